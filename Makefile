@@ -1,0 +1,38 @@
+# Top-level build: the product library (HIP, gfx950 only) and the checkers (oracle/).
+# `python -c "import __graft_entry__ as g; g.build()"` drives the same commands.
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+LIBDIR   := pathtracer_amd/lib
+CSRC     := pathtracer_amd/csrc
+HOST     := pathtracer_amd/host
+# -ffp-contract=off: value-carrying arithmetic keeps the reference's rounding; the sphere search re-enables
+# contraction locally with `#pragma clang fp contract(fast)` (pt_device.h).
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
+CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Wall
+
+all: lib oracle
+
+lib: $(LIBDIR)/libpt_hip.so
+
+$(LIBDIR)/pt_hip.o: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h include/pt_hip.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/pt_world.o: $(HOST)/pt_world.cpp $(HOST)/pt_world.h include/pt_hip.h
+	@mkdir -p $(LIBDIR)
+	g++ $(CXXFLAGS) -c $< -o $@
+
+$(LIBDIR)/libpt_hip.so: $(LIBDIR)/pt_hip.o $(LIBDIR)/pt_world.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@
+
+oracle:
+	$(MAKE) -C oracle all
+
+isa: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h
+	@mkdir -p $(LIBDIR)/isa
+	$(HIPCC) $(HIPFLAGS) -save-temps=obj -Rpass-analysis=kernel-resource-usage -c $< -o $(LIBDIR)/isa/pt_hip.o 2> $(LIBDIR)/isa/resource_usage.txt || (cat $(LIBDIR)/isa/resource_usage.txt; false)
+
+clean:
+	rm -rf $(LIBDIR) ; $(MAKE) -C oracle clean
+
+.PHONY: all lib oracle isa clean

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X path tracer (contract: see the task's bench section).
+
+Metric   : Msamples/s, whole job (BASELINE.json: "Msamples/s (whole node) book-1 scene 1080p @1/2/4/8 GPUs").
+Workload : BASELINE.json configs[2] geometry -- init_test_scene_1 (book-1 final: 259 spheres + 1 plane), 1920x1080,
+           depth 50, 512 spp PER GPU (4096 spp split across 8 GPUs) -- so per-GPU work is fixed as N grows (weak
+           scaling): rank r renders global sample indices [r*512, (r+1)*512) of every pixel.
+Step     : one complete frame: render kernel -> (N>1) RCCL all-reduce of the float accumulation buffer -> device
+           resolve (clamp(mean), gamma, BGRA pack).  Scene and output buffers are resident in HBM before the timed
+           region; the PCIe read-back of the 8 MB BGRA image is outside it (DESIGN.md quotes the PCIe-inclusive rate).
+One rank per GPU; for N>1 launch with torch.distributed.run (reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
+
+
+def flops_per_sample(sbar, n_spheres, n_planes, moving):
+    """Algorithmic FLOPs of the brute-force formulation, SURVEY.md 8(d):
+    ray-gen 90 + per segment (14/plane + 25|31/sphere) + 75 per hit-segment shading + 8 sky terminal."""
+    f_sph = 31.0 if moving else 25.0
+    return 90.0 + sbar * (14.0 * n_planes + f_sph * n_spheres) + (sbar - 1.0) * 75.0 + 8.0
+
+
+def cpu_baseline(scene_id, w, h, depth, spp, threads):
+    """The reference's own renderer (compiled into oracle/_ref) -- or, where that library is absent, our CPU
+    restatement -- timed on the host cores on a bounded sample of the same workload (same scene, resolution and
+    depth; fewer spp -- Msamples/s does not depend on spp)."""
+    from oracle import pyoracle as po
+    import pathtracer_amd as pt
+    from tests._util import to_scene_arrays
+    sa = to_scene_arrays(pt.Scene.builtin(scene_id, w / h))
+    if po.Ref.available():
+        R = po.Ref()
+        hs = R.scene_from_arrays(sa)
+        R.build_bvh(hs, 0)
+        secs, _ = R.render(hs, w, h, spp, depth, threads)
+        R.scene_free(hs)
+        kind = "reference"
+    else:
+        O = po.Oracle()
+        hs = O.scene(sa)
+        secs, _, _ = O.time_render_philox(hs, w, h, 0, spp, depth, 0, threads)
+        O.scene_free(hs)
+        kind = "port"
+    return {"value": round(w * h * spp / secs / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": kind,
+            "sample": f"scene {scene_id} {w}x{h} depth {depth}, {spp} spp ({w * h * spp / 1e6:.1f} Msamples, {secs:.1f} s wall)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp-per-gpu", type=int, default=512)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import pathtracer_amd as pt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available() or pt.device_count() <= local_rank:
+        print("bench.py: no HIP device visible -- the product path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+
+    w, h, S, depth = args.width, args.height, args.spp_per_gpu, args.depth
+    scene = pt.Scene.builtin(args.scene, w / h)
+    r = pt.Renderer(local_rank)
+    r.upload(scene)
+    accum = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
+    bgra = torch.empty((h, w), dtype=torch.int32, device=dev)
+    params = r.params(w, h, rank * S, (rank + 1) * S, depth, seed=args.seed)
+    stream = torch.cuda.current_stream(dev)
+
+    def step(ev=None):
+        if ev:
+            ev[0].record(stream)
+        r.render_device(params, accum.data_ptr(), stream.cuda_stream)
+        if ev:
+            ev[1].record(stream)
+        if world > 1:
+            dist.all_reduce(accum, op=dist.ReduceOp.SUM)  # float accumulation buffer over xGMI, before tonemapping
+        if rank == 0:
+            r.resolve_device(accum.data_ptr(), w * h, S * world, 0, bgra.data_ptr(), stream.cuda_stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+    st = r.stats()  # last launch: samples, segments (S-bar), library's own HIP-event time
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        seg = torch.tensor([float(st["segments"]), float(st["samples"]), kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+        segs, smps, kernel_ms = float(seg[0]), float(seg[1]), float(seg[2]) / world
+    else:
+        segs, smps = float(st["segments"]), float(st["samples"])
+
+    host_img = bgra.cpu() if rank == 0 else None  # outside the timed region (PCIe)
+    if rank == 0:
+        samples_per_step = w * h * S * world
+        value = samples_per_step * args.steps / elapsed / 1e6
+        sbar = segs / smps
+        moving = scene.vel is not None
+        f_sample = flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving)
+        # roofline of the dominant kernel (k_render_lds), per launch on one GPU
+        achieved = (w * h * S) * f_sample / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                t = json.load(open(tf))
+                key = f"scene{args.scene}_{w}x{h}_spp{S}_d{depth}"
+                traffic = t.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "Msamples/s (whole node) book-1 scene 1080p", "value": round(value, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"init_test_scene_{args.scene} (book-1 final, {scene.n_spheres} spheres + {scene.n_planes} plane) "
+                                   f"{w}x{h}, depth {depth}, {S} spp per GPU = {S * world} spp total",
+                       "global_samples_per_step": samples_per_step, "parallelism": f"spp-split x{world} + RCCL all-reduce(sum) of the f32 accumulation buffer",
+                       "segments_per_sample": round(sbar, 4), "kernel_ms": round(kernel_ms, 3), "lib_kernel_ms_last": round(st["kernel_ms"], 3)},
+            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                         "kernel": "k_render_lds", "flop_per_sample": round(f_sample, 1),
+                         "note": "FP32 vector (VALU) roofline, not MFMA: BASELINE.json north_star; algorithmic FLOPs per SURVEY.md 8(d)"},
+        }
+        if world == 1 and args.cpu_spp > 0:
+            threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+            out["cpu_baseline"] = cpu_baseline(args.scene, w, h, depth, args.cpu_spp, threads)
+            out["config"]["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        assert host_img is not None and host_img.shape == (h, w)
+        print(json.dumps(out))
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+/* pt_hip.h -- C-ABI of the MI355X-native path tracer (libpt_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of DeveloperDenis/PathTracer: the span the reference times as
+ * "PathTracing" (src/main.cpp:412-481), i.e. every call of run_thread_batch (src/main.cpp:334-362) and what
+ * it calls -- Camera::get_ray (src/camera.cpp:57-79), cast_ray (src/main.cpp:171-307), the sphere / plane /
+ * BVH intersection (src/geometry.cpp:39-115, src/main.cpp:53-91) and the diffuse / metal / dielectric scatter
+ * with its samplers (src/utils.h:71-138).  The reference has no plugin or FFI interface; the
+ * one seam is the thread-pool work item `run_thread_batch(.., ThreadData*, ..)` whose inputs are a read-only
+ * World + Camera + BVH and whose output is Image.pixels.  The functions below take exactly those inputs
+ * (flattened to plain arrays) and produce exactly that output; INTEGRATION.md shows the 30-line change to
+ * the reference's main() that binds them.
+ *
+ * Conventions: every entry point returns an int status (0 = PT_OK, negative = pt_status); nothing aborts or
+ * throws across the boundary (the reference is built /EHa- /GR-, src/build.bat:7).  The caller owns all host
+ * buffers before and after each call; the library copies on upload and owns its device memory inside pt_ctx.
+ * A pt_ctx is bound to one GPU and is driven by one host thread at a time; distinct contexts are independent.
+ * The result depends only on (scene, params): never on the GPU count, launch geometry or scheduling, because
+ * the RNG is Philox4x32-10 keyed by (seed, pixel, global sample index)  (DESIGN.md "RNG").
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_ctx pt_ctx;
+typedef struct pt_scene pt_scene;
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,     /* NULL pointer, zero size, inconsistent counts */
+    PT_ERR_NO_DEVICE = -2,   /* no such GPU / HIP runtime unavailable */
+    PT_ERR_HIP = -3,         /* a HIP call failed; pt_hip_last_error(ctx) has the text */
+    PT_ERR_NO_SCENE = -4,    /* render / probe before pt_hip_upload_scene */
+    PT_ERR_UNSUPPORTED = -5, /* e.g. more planes than the reference's 64 (src/render_world.h:88) */
+    PT_ERR_IO = -6           /* file could not be written */
+} pt_status;
+
+/* Material::Type, src/render_world.h:32-38 (same numeric values, same spelling of DIALECTRIC) */
+typedef enum pt_material_type { PT_MAT_NONE = 0, PT_MAT_DIFFUSE = 1, PT_MAT_METAL = 2, PT_MAT_DIALECTRIC = 3 } pt_material_type;
+
+/* Flattened World + Camera (src/render_world.h:57-96, src/camera.h:9-38).  All arrays are caller-owned. */
+typedef struct pt_scene_desc {
+    uint32_t n_spheres;
+    const float* sphere_pos_r;       /* 4*n : Sphere{pos.xyz, radius}                 src/geometry.h:16-23   */
+    const float* sphere_vel;         /* 3*n : SphereObject::velocity, or NULL = static src/render_world.h:64  */
+    const uint32_t* sphere_mat_type; /*   n : Material::type                           src/render_world.h:40  */
+    const float* sphere_mat_rgba;    /* 4*n : Material::colour (alpha included)        src/render_world.h:41  */
+    const float* sphere_mat_param;   /* 2*n : Material::roughness, Material::n         src/render_world.h:44,47 */
+    uint32_t n_planes;               /* <= 64                                          src/render_world.h:88  */
+    const float* plane_n_d;          /* 4*np: Plane{normal.xyz, offset}                src/geometry.h:25-29   */
+    const uint32_t* plane_mat_type;
+    const float* plane_mat_rgba;
+    const float* plane_mat_param;
+    float t0, t1;                    /* World::startTime, endTime                      src/render_world.h:91-92 */
+    float camera[13];                /* pos[3] dir[3] up[3] fov(rad) aspect focusDistance lensRadius  src/camera.h:14-21,37 */
+} pt_scene_desc;
+
+/* The reference's compile-time settings (src/main.cpp:29-42) as run-time parameters. */
+typedef struct pt_params {
+    uint32_t width, height;       /* Image::width/height, src/image.h:4-9 */
+    uint32_t spp_begin, spp_end;  /* global sample indices [begin,end) of SAMPLES_PER_PIXEL rendered by this call */
+    uint32_t max_depth;           /* MAX_RAY_DEPTH */
+    uint32_t flags;               /* PT_FLAG_* */
+    uint64_t seed;                /* Philox key */
+} pt_params;
+
+#define PT_FLAG_STRICT_SEARCH 1u /* closest-sphere search in reference arithmetic for every sphere (slow; parity tests) */
+#define PT_FLAG_FORCE_BVH 2u     /* use the HBM BVH kernel even if the scene fits in LDS */
+#define PT_FLAG_FORCE_LDS 4u     /* fail with PT_ERR_UNSUPPORTED instead of falling back to the BVH kernel */
+
+typedef struct pt_stats {
+    uint64_t samples;       /* width*height*(spp_end-spp_begin) */
+    uint64_t segments;      /* loop iterations of cast_ray over all samples (S-bar = segments/samples) */
+    uint64_t sphere_tests;  /* ray-sphere evaluations (LDS kernel: segments*n_spheres; BVH kernel: leaves visited) */
+    uint64_t node_visits;   /* BVH kernel: box tests; LDS kernel: 0 */
+    double kernel_ms;       /* HIP-event time of the render kernel on its stream */
+    uint32_t kernel;        /* 0 = LDS brute force, 1 = BVH in HBM */
+    uint32_t reserved;
+} pt_stats;
+
+/* ---- device / context -------------------------------------------------------------------------------- */
+int pt_hip_device_count(void);
+int pt_hip_create(int device, pt_ctx** out);
+void pt_hip_destroy(pt_ctx* ctx);
+const char* pt_hip_strerror(int status);
+const char* pt_hip_last_error(pt_ctx* ctx);
+
+/* Replaces: World/Camera being handed to the workers through ThreadData (src/main.cpp:421-427) and
+ * build_bvh_tree (src/main.cpp:402).  Copies the scene, lays it out for the device, builds the BVH if needed. */
+int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* scene);
+
+/* Replaces: the thread-pool submit + join over all 32x32 blocks (src/main.cpp:415-477).
+ * accum_rgba_host: width*height*4 floats, row-major top-down like Image.pixels (src/image.h:11-14); receives the
+ * per-pixel SUM of the samples [spp_begin,spp_end) (not the mean: partial sums of several GPUs / calls add up;
+ * pt_resolve() turns the total into the reference's clamp(mean) pixels).  Synchronous. */
+int pt_hip_render(pt_ctx* ctx, const pt_params* params, float* accum_rgba_host);
+
+/* Same, into caller-owned DEVICE memory on a caller-owned stream (hipStream_t as void*; NULL = default stream).
+ * Asynchronous: returns after enqueueing.  This is what a multi-GPU driver all-reduces (RCCL) before resolving. */
+int pt_hip_render_device(pt_ctx* ctx, const pt_params* params, float* accum_rgba_dev, void* stream);
+
+/* Statistics of the last render on this context (synchronises with it). */
+int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out);
+
+/* Replaces: `clamp(pixelColour/SAMPLES_PER_PIXEL, 0, 1)` (src/main.cpp:358) and the per-pixel part of
+ * write_image_to_bmp (src/file_io.h:29-45: gamma-2 sqrt, (u8)(255*c) truncation, 0xAARRGGBB) -- on the device, so
+ * only 4 bytes per pixel need to cross PCIe.  Either output may be NULL.  Device pointers, asynchronous. */
+int pt_hip_resolve_device(pt_ctx* ctx, const float* accum_rgba_dev, uint32_t n_pixels, uint32_t spp_total,
+                          float* pixels_rgba_dev, uint32_t* bgra_dev, void* stream);
+
+/* ---- host-side pieces that stay host-side in the reference ------------------------------------------- */
+/* clamp(sum * (1.0f/spp), 0, 1) on the host (src/main.cpp:358, src/vectors.cpp:100-103, src/utils.h:17-20). */
+int pt_resolve(const float* accum_rgba, uint32_t n_pixels, uint32_t spp_total, float* pixels_rgba);
+/* src/file_io.h:29-45 per pixel. */
+int pt_pack_bgra(const float* pixels_rgba, uint32_t n_pixels, uint32_t* bgra);
+/* write_image_to_bmp (src/file_io.h:4-52): 58-byte header + top-down 32-bpp BGRA.  Byte-identical format. */
+int pt_bmp_write(const char* path, const float* pixels_rgba, uint32_t width, uint32_t height);
+int pt_bmp_write_bgra(const char* path, const uint32_t* bgra, uint32_t width, uint32_t height);
+/* Header only (58 bytes), for tests. */
+int pt_bmp_header(uint32_t width, uint32_t height, uint8_t* out58);
+
+/* Scene builders: init_test_scene_{1,2,3} (src/scene_init.cpp:35-177) re-expressed on std::mt19937 so they
+ * produce the scenes the reference produces under libstdc++; id 4 = the materials/DOF test scene (C2) and
+ * id 5 = n_spheres random spheres (C5) defined in SURVEY.md 8(d).  The returned handle owns the arrays that
+ * pt_scene_get_desc() points into. */
+pt_scene* pt_scene_builtin(int scene_id, float aspect_ratio, uint32_t n_spheres_for_id5);
+int pt_scene_get_desc(const pt_scene* scene, pt_scene_desc* out);
+void pt_scene_free(pt_scene* scene);
+
+/* ---- parity probes: the product's own device functions on caller-supplied inputs ---------------------- */
+/* All pointers are HOST pointers; n records; synchronous.  They run the same device code as the render kernels
+ * (same LDS staging, same search, same scatter) with the RNG replaced by an explicit tape of uniforms, so the
+ * reference, the oracle and the GPU can be compared on IDENTICAL inputs (BASELINE.json north_star, gate 1). */
+
+/* Closest hit of planes then spheres as cast_ray orders it (src/main.cpp:180-216).
+ * rays: 6*n (origin, unit dir); times: n; out_prim: sphere index >= 0, plane i -> -1-i, miss -> INT32_MIN. */
+int pt_hip_probe_hits(pt_ctx* ctx, uint32_t n, const float* rays, const float* times, uint32_t flags,
+                      float* out_t, int32_t* out_prim, float* out_point, float* out_normal);
+/* Camera::get_ray (src/camera.cpp:57-79) for n (u,v) pairs; ray i draws from tape[ofs[i] .. ofs[i+1]). */
+int pt_hip_probe_get_rays(pt_ctx* ctx, uint32_t n, const float* uv, const float* tape, const uint64_t* ofs, float* out_rays);
+/* One scatter event (src/main.cpp:219-298) per record.  out_event: 0 scattered, 3 absorbed, 4 NONE material;
+ * bit 31 set = tape overrun. */
+int pt_hip_probe_scatter(pt_ctx* ctx, uint32_t n, const float* dirs, const float* points, const float* normals,
+                         const uint32_t* mat_type, const float* mat_rgba, const float* mat_param,
+                         const float* tape32, const uint64_t* ofs32, const double* tape64, const uint64_t* ofs64,
+                         float* out_dir, uint32_t* out_event);
+/* cast_ray (src/main.cpp:171-307) for n rays on per-ray tapes. out_rgba 4*n; out_segments n (may be NULL). */
+int pt_hip_probe_paths(pt_ctx* ctx, uint32_t n, const float* rays, const float* times, uint32_t max_depth, uint32_t flags,
+                       const float* tape32, const uint64_t* ofs32, const double* tape64, const uint64_t* ofs64,
+                       float* out_rgba, uint32_t* out_segments);
+/* One sample of run_thread_batch's loop (src/main.cpp:349-355) per record on the Philox stream of
+ * (params->seed, pixels[i], samples[i]); out_rgba 4*n; out_segments n (may be NULL). */
+int pt_hip_probe_samples(pt_ctx* ctx, const pt_params* params, uint32_t n, const uint32_t* pixels, const uint32_t* samples,
+                         float* out_rgba, uint32_t* out_segments);
+/* First n words of the Philox stream of (seed, pixel, sample), generated on the device. */
+int pt_hip_probe_philox(pt_ctx* ctx, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* out_words);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_HIP_H */

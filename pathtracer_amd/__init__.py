@@ -1,0 +1,318 @@
+"""pathtracer_amd -- Python face of libpt_hip.so (include/pt_hip.h).
+
+Thin ctypes plumbing for tests, bench.py and the multi-GPU driver: every call goes through the C-ABI, nothing is
+computed in Python and there is NO CPU fallback -- if the HIP library is missing or no MI355X is visible the calls
+raise.  Device buffers handed in/out are raw addresses (ints), e.g. ``torch.Tensor.data_ptr()``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
+
+PT_OK = 0
+PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_UNSUPPORTED, PT_ERR_IO = -1, -2, -3, -4, -5, -6
+MAT_NONE, MAT_DIFFUSE, MAT_METAL, MAT_DIALECTRIC = 0, 1, 2, 3
+FLAG_STRICT_SEARCH, FLAG_FORCE_BVH, FLAG_FORCE_LDS = 1, 2, 4
+PRIM_MISS = -(2 ** 31)
+
+# Every symbol include/pt_hip.h declares (tests/test_abi.py checks the library exports exactly these).
+EXPORTS = (
+    "pt_hip_device_count", "pt_hip_create", "pt_hip_destroy", "pt_hip_strerror", "pt_hip_last_error",
+    "pt_hip_upload_scene", "pt_hip_render", "pt_hip_render_device", "pt_hip_last_stats", "pt_hip_resolve_device",
+    "pt_resolve", "pt_pack_bgra", "pt_bmp_write", "pt_bmp_write_bgra", "pt_bmp_header",
+    "pt_scene_builtin", "pt_scene_get_desc", "pt_scene_free",
+    "pt_hip_probe_hits", "pt_hip_probe_get_rays", "pt_hip_probe_scatter", "pt_hip_probe_paths",
+    "pt_hip_probe_samples", "pt_hip_probe_philox",
+)
+
+
+class PtError(RuntimeError):
+    def __init__(self, status, what, detail=""):
+        self.status = status
+        super().__init__(f"{what}: status {status} ({_strerror(status)}){' -- ' + detail if detail else ''}")
+
+
+class SceneDesc(C.Structure):  # pt_scene_desc
+    _fields_ = [
+        ("n_spheres", C.c_uint32), ("sphere_pos_r", C.c_void_p), ("sphere_vel", C.c_void_p),
+        ("sphere_mat_type", C.c_void_p), ("sphere_mat_rgba", C.c_void_p), ("sphere_mat_param", C.c_void_p),
+        ("n_planes", C.c_uint32), ("plane_n_d", C.c_void_p), ("plane_mat_type", C.c_void_p),
+        ("plane_mat_rgba", C.c_void_p), ("plane_mat_param", C.c_void_p),
+        ("t0", C.c_float), ("t1", C.c_float), ("camera", C.c_float * 13),
+    ]
+
+
+class Params(C.Structure):  # pt_params
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp_begin", C.c_uint32), ("spp_end", C.c_uint32),
+                ("max_depth", C.c_uint32), ("flags", C.c_uint32), ("seed", C.c_uint64)]
+
+
+class Stats(C.Structure):  # pt_stats
+    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64), ("node_visits", C.c_uint64),
+                ("kernel_ms", C.c_double), ("kernel", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+_lib = None
+
+
+def load_library(path=LIB_PATH):
+    """Load libpt_hip.so; raises if it was not built (run `make lib` or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} is missing: build it with `make lib` (hipcc --offload-arch=gfx950); "
+                                "there is no CPU fallback")
+    L = C.CDLL(path)
+    L.pt_hip_strerror.restype = C.c_char_p
+    L.pt_hip_last_error.restype = C.c_char_p
+    L.pt_hip_last_error.argtypes = [C.c_void_p]
+    L.pt_scene_builtin.restype = C.c_void_p
+    L.pt_scene_builtin.argtypes = [C.c_int, C.c_float, C.c_uint32]
+    L.pt_scene_get_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+    L.pt_scene_free.argtypes = [C.c_void_p]
+    L.pt_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.pt_hip_destroy.argtypes = [C.c_void_p]
+    L.pt_hip_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+    L.pt_hip_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p]
+    L.pt_hip_render_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]
+    L.pt_hip_last_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.pt_hip_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _strerror(status):
+    try:
+        return load_library().pt_hip_strerror(C.c_int(status)).decode()
+    except Exception:  # noqa: BLE001 - only used to decorate another error
+        return "?"
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class Scene:
+    """Flat scene arrays + the pt_scene_desc that points into them (keeps the arrays alive)."""
+
+    def __init__(self, pos_r, vel, mtype, rgba, param, pl_n_d, pl_type, pl_rgba, pl_param, t0, t1, camera13):
+        self.pos_r = _f32(pos_r).reshape(-1, 4)
+        n = len(self.pos_r)
+        self.vel = None if vel is None else _f32(vel).reshape(-1, 3)
+        self.mtype, self.rgba, self.param = _u32(mtype).reshape(-1), _f32(rgba).reshape(-1, 4), _f32(param).reshape(-1, 2)
+        self.pl_n_d, self.pl_type = _f32(pl_n_d).reshape(-1, 4), _u32(pl_type).reshape(-1)
+        self.pl_rgba, self.pl_param = _f32(pl_rgba).reshape(-1, 4), _f32(pl_param).reshape(-1, 2)
+        self.t0, self.t1, self.camera = float(t0), float(t1), _f32(camera13).reshape(13)
+        if not (len(self.mtype) == len(self.rgba) == len(self.param) == n) or (self.vel is not None and len(self.vel) != n):
+            raise ValueError("sphere arrays disagree in length")
+        if not (len(self.pl_type) == len(self.pl_rgba) == len(self.pl_param) == len(self.pl_n_d)):
+            raise ValueError("plane arrays disagree in length")
+        d = self.desc = SceneDesc()
+        d.n_spheres, d.n_planes = n, len(self.pl_n_d)
+        d.sphere_pos_r, d.sphere_vel = self.pos_r.ctypes.data, (None if self.vel is None else self.vel.ctypes.data)
+        d.sphere_mat_type, d.sphere_mat_rgba, d.sphere_mat_param = self.mtype.ctypes.data, self.rgba.ctypes.data, self.param.ctypes.data
+        d.plane_n_d, d.plane_mat_type = self.pl_n_d.ctypes.data, self.pl_type.ctypes.data
+        d.plane_mat_rgba, d.plane_mat_param = self.pl_rgba.ctypes.data, self.pl_param.ctypes.data
+        d.t0, d.t1 = self.t0, self.t1
+        for i in range(13):
+            d.camera[i] = float(self.camera[i])
+
+    @property
+    def n_spheres(self):
+        return len(self.pos_r)
+
+    @property
+    def n_planes(self):
+        return len(self.pl_n_d)
+
+    @staticmethod
+    def builtin(scene_id, aspect, n_spheres=0):
+        """init_test_scene_{1,2,3} / materials (4) / random spheres (5) via the library's host-side builders."""
+        L = load_library()
+        h = L.pt_scene_builtin(scene_id, aspect, n_spheres)
+        if not h:
+            raise PtError(PT_ERR_INVALID, f"pt_scene_builtin({scene_id})")
+        try:
+            d = SceneDesc()
+            st = L.pt_scene_get_desc(h, C.byref(d))
+            if st != PT_OK:
+                raise PtError(st, "pt_scene_get_desc")
+
+            def arr(ptr, n, dt):
+                if not ptr or n == 0:
+                    return np.zeros(n, dt)
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float if dt == np.float32 else C.c_uint32)), (n,)).astype(dt).copy()
+
+            ns, npl = d.n_spheres, d.n_planes
+            return Scene(arr(d.sphere_pos_r, 4 * ns, np.float32), arr(d.sphere_vel, 3 * ns, np.float32) if d.sphere_vel else None,
+                         arr(d.sphere_mat_type, ns, np.uint32), arr(d.sphere_mat_rgba, 4 * ns, np.float32),
+                         arr(d.sphere_mat_param, 2 * ns, np.float32), arr(d.plane_n_d, 4 * npl, np.float32),
+                         arr(d.plane_mat_type, npl, np.uint32), arr(d.plane_mat_rgba, 4 * npl, np.float32),
+                         arr(d.plane_mat_param, 2 * npl, np.float32), d.t0, d.t1, np.array(list(d.camera), np.float32))
+        finally:
+            L.pt_scene_free(h)
+
+
+def device_count():
+    return int(load_library().pt_hip_device_count())
+
+
+class Renderer:
+    """One pt_ctx: one GPU, one host thread at a time."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        st = self.L.pt_hip_create(device, C.byref(h))
+        if st != PT_OK:
+            raise PtError(st, f"pt_hip_create(device={device})")
+        self.h = h
+        self.scene = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pt_hip_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _check(self, st, what):
+        if st != PT_OK:
+            raise PtError(st, what, self.L.pt_hip_last_error(self.h).decode() if st == PT_ERR_HIP else "")
+
+    def upload(self, scene: Scene):
+        self._check(self.L.pt_hip_upload_scene(self.h, C.byref(scene.desc)), "pt_hip_upload_scene")
+        self.scene = scene
+
+    @staticmethod
+    def params(width, height, spp_begin, spp_end, max_depth, seed=0, flags=0):
+        return Params(width, height, spp_begin, spp_end, max_depth, flags, seed)
+
+    def render(self, width, height, spp_begin, spp_end, max_depth, seed=0, flags=0):
+        """-> (height, width, 4) float32 per-pixel SUM over samples [spp_begin, spp_end)."""
+        out = np.empty((height, width, 4), np.float32)
+        p = self.params(width, height, spp_begin, spp_end, max_depth, seed, flags)
+        self._check(self.L.pt_hip_render(self.h, C.byref(p), _ptr(out)), "pt_hip_render")
+        return out
+
+    def render_device(self, params: Params, accum_dev_ptr: int, stream: int = 0):
+        self._check(self.L.pt_hip_render_device(self.h, C.byref(params), C.c_void_p(accum_dev_ptr), C.c_void_p(stream)), "pt_hip_render_device")
+
+    def resolve_device(self, accum_dev_ptr, n_pixels, spp_total, pixels_dev_ptr=0, bgra_dev_ptr=0, stream=0):
+        self._check(self.L.pt_hip_resolve_device(self.h, C.c_void_p(accum_dev_ptr), n_pixels, spp_total,
+                                                 C.c_void_p(pixels_dev_ptr) if pixels_dev_ptr else None,
+                                                 C.c_void_p(bgra_dev_ptr) if bgra_dev_ptr else None, C.c_void_p(stream)), "pt_hip_resolve_device")
+
+    def stats(self):
+        s = Stats()
+        self._check(self.L.pt_hip_last_stats(self.h, C.byref(s)), "pt_hip_last_stats")
+        return {k: getattr(s, k) for k, _ in Stats._fields_ if k != "reserved"}
+
+    # ---- parity probes
+    def probe_hits(self, rays, times, flags=0):
+        rays, times = _f32(rays).reshape(-1, 6), _f32(times).reshape(-1)
+        n = len(rays)
+        t, prim = np.zeros(n, np.float32), np.zeros(n, np.int32)
+        pt, nr = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        self._check(self.L.pt_hip_probe_hits(self.h, C.c_uint32(n), _ptr(rays), _ptr(times), C.c_uint32(flags), _ptr(t), _ptr(prim), _ptr(pt), _ptr(nr)), "pt_hip_probe_hits")
+        return t, prim, pt, nr
+
+    def probe_get_rays(self, uv, tape, ofs):
+        uv, tape, ofs = _f32(uv).reshape(-1, 2), _f32(tape), _u64(ofs)
+        out = np.zeros((len(uv), 6), np.float32)
+        self._check(self.L.pt_hip_probe_get_rays(self.h, C.c_uint32(len(uv)), _ptr(uv), _ptr(tape), _ptr(ofs), _ptr(out)), "pt_hip_probe_get_rays")
+        return out
+
+    def probe_scatter(self, dirs, points, normals, mtype, rgba, param, tape32, ofs32, tape64, ofs64):
+        dirs, points, normals = _f32(dirs).reshape(-1, 3), _f32(points).reshape(-1, 3), _f32(normals).reshape(-1, 3)
+        mtype, rgba, param = _u32(mtype), _f32(rgba), _f32(param)
+        tape32, ofs32, ofs64 = _f32(tape32), _u64(ofs32), _u64(ofs64)
+        tape64 = np.ascontiguousarray(tape64, np.float64)
+        n = len(dirs)
+        out, ev = np.zeros((n, 3), np.float32), np.zeros(n, np.uint32)
+        self._check(self.L.pt_hip_probe_scatter(self.h, C.c_uint32(n), _ptr(dirs), _ptr(points), _ptr(normals), _ptr(mtype), _ptr(rgba), _ptr(param),
+                                                _ptr(tape32), _ptr(ofs32), _ptr(tape64), _ptr(ofs64), _ptr(out), _ptr(ev)), "pt_hip_probe_scatter")
+        return out, ev
+
+    def probe_paths(self, rays, times, max_depth, tape32, ofs32, tape64, ofs64, flags=0):
+        rays, times = _f32(rays).reshape(-1, 6), _f32(times).reshape(-1)
+        tape32, ofs32, ofs64 = _f32(tape32), _u64(ofs32), _u64(ofs64)
+        tape64 = np.ascontiguousarray(tape64, np.float64)
+        n = len(rays)
+        out, segs = np.zeros((n, 4), np.float32), np.zeros(n, np.uint32)
+        self._check(self.L.pt_hip_probe_paths(self.h, C.c_uint32(n), _ptr(rays), _ptr(times), C.c_uint32(max_depth), C.c_uint32(flags),
+                                              _ptr(tape32), _ptr(ofs32), _ptr(tape64), _ptr(ofs64), _ptr(out), _ptr(segs)), "pt_hip_probe_paths")
+        return out, segs
+
+    def probe_samples(self, width, height, pixels, samples, max_depth, seed=0, flags=0):
+        pixels, samples = _u32(pixels), _u32(samples)
+        n = len(pixels)
+        out, segs = np.zeros((n, 4), np.float32), np.zeros(n, np.uint32)
+        p = self.params(width, height, 0, 1, max_depth, seed, flags)
+        self._check(self.L.pt_hip_probe_samples(self.h, C.byref(p), C.c_uint32(n), _ptr(pixels), _ptr(samples), _ptr(out), _ptr(segs)), "pt_hip_probe_samples")
+        return out, segs
+
+    def probe_philox(self, seed, pixel, sample, n):
+        out = np.zeros(n, np.uint32)
+        self._check(self.L.pt_hip_probe_philox(self.h, C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_uint32(n), _ptr(out)), "pt_hip_probe_philox")
+        return out
+
+
+# ---- host-only helpers (no GPU needed) -----------------------------------------------------------------------
+def resolve(sum_rgba, spp_total):
+    s = _f32(sum_rgba)
+    out = np.empty_like(s)
+    st = load_library().pt_resolve(_ptr(s), C.c_uint32(s.size // 4), C.c_uint32(spp_total), _ptr(out))
+    if st != PT_OK:
+        raise PtError(st, "pt_resolve")
+    return out
+
+
+def pack_bgra(pixels_rgba):
+    p = _f32(pixels_rgba)
+    out = np.empty(p.size // 4, np.uint32)
+    st = load_library().pt_pack_bgra(_ptr(p), C.c_uint32(p.size // 4), _ptr(out))
+    if st != PT_OK:
+        raise PtError(st, "pt_pack_bgra")
+    return out
+
+
+def bmp_header(width, height):
+    out = np.zeros(58, np.uint8)
+    st = load_library().pt_bmp_header(C.c_uint32(width), C.c_uint32(height), _ptr(out))
+    if st != PT_OK:
+        raise PtError(st, "pt_bmp_header")
+    return out
+
+
+def bmp_write(path, pixels_rgba, width, height):
+    p = _f32(pixels_rgba)
+    st = load_library().pt_bmp_write(os.fsencode(path), _ptr(p), C.c_uint32(width), C.c_uint32(height))
+    if st != PT_OK:
+        raise PtError(st, f"pt_bmp_write({path})")

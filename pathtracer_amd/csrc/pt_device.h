@@ -1,0 +1,464 @@
+// pt_device.h -- device functions of the MI355X path tracer (gfx950, wave64).
+//
+// Two arithmetic regimes live here, on purpose (DESIGN.md "Arithmetic"):
+//   * everything a result VALUE flows through (ray generation, the chosen hit's t, hit point, normal, scatter
+//     directions, colours) is evaluated in the reference's own operation order with contraction OFF, so it is
+//     bit-identical to the reference/oracle on identical inputs;
+//   * the closest-sphere SEARCH over the LDS-resident scene -- >80 % of all instructions -- only has to pick the
+//     right sphere index, so it runs contracted, packed (v_pk_fma_f32) and with the hardware sqrt.
+// Reference citations are file:line under /root/reference/src.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace ptd {
+
+#define PT_DEV __device__ __forceinline__
+
+constexpr float kF32Max = 3.402823466e+38F; // types.h:9
+constexpr float kMinT = 0.001f;             // main.cpp:56,178
+constexpr int32_t kPrimMiss = INT32_MIN;
+
+enum : uint32_t { MAT_NONE = 0, MAT_DIFFUSE = 1, MAT_METAL = 2, MAT_DIALECTRIC = 3 }; // render_world.h:32-38
+enum : uint32_t { EV_SCATTER = 0, EV_SKY = 1, EV_DEPTH = 2, EV_ABSORB = 3, EV_NONE_MAT = 4 };
+
+// ------------------------------------------------------------------ vectors.h / vectors.cpp (strict)
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+PT_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV V4 v4(float x, float y, float z, float w) { V4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+PT_DEV V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }   // vectors.cpp:13-20
+PT_DEV V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }   // vectors.cpp:22-29
+PT_DEV V3 mul(V3 v, float s) { return v3(v.x * s, v.y * s, v.z * s); }      // vectors.cpp:31-42
+PT_DEV V3 neg(V3 v) { return v3(-v.x, -v.y, -v.z); }                        // vectors.cpp:49-56
+PT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   // vectors.cpp:132-135
+PT_DEV float norm_squared(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; } // vectors.cpp:112-115
+PT_DEV float norm(V3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); } // vectors.cpp:107-110 (correctly rounded sqrt)
+PT_DEV V3 normalize(V3 v) { return mul(v, 1.0f / norm(v)); }                // vectors.cpp:44-47,127-130
+PT_DEV bool near_zero(V3 v)                                                 // vectors.cpp:144-148
+{
+    const float e = 1e-8f;
+    return fabsf(v.x) < e && fabsf(v.y) < e && fabsf(v.z) < e;
+}
+PT_DEV V4 hadamard(V4 a, V4 b) { return v4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); } // vectors.cpp:150-158
+
+struct Ray { V3 o, d; };
+PT_DEV V3 ray_at(const Ray& r, float t) { return add(r.o, mul(r.d, t)); }   // geometry.h:10
+PT_DEV V3 reflect_direction(V3 dir, V3 n)                                   // geometry.h:62-67
+{
+    float projectedDistance = -dot(dir, n);
+    return add(dir, mul(mul(n, 2.0f), projectedDistance));
+}
+
+// ------------------------------------------------------------------ RNG back-ends
+// Philox4x32-10 stream of (seed, pixel, sample): word k = philox(ctr={k>>2,pixel,sample,0}, key=seed)[k&3]
+// (defined in DESIGN.md "RNG"; pinned by the Random123 known-answer vectors and against the oracle).
+PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* o)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r)
+    {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+struct PhiloxRng
+{
+    uint32_t k0, k1, pixel, sample, k;
+    uint32_t b0, b1, b2, b3; // words k, k+1, .. of the current block, shifted down as they are consumed
+    PT_DEV void init(uint64_t seed, uint32_t px, uint32_t smp)
+    {
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32); pixel = px; sample = smp; k = 0;
+        b0 = b1 = b2 = b3 = 0;
+    }
+    PT_DEV uint32_t word()
+    {
+        if ((k & 3u) == 0u)
+        {
+            uint32_t o[4];
+            philox4x32_10(k >> 2, pixel, sample, 0u, k0, k1, o);
+            b0 = o[0]; b1 = o[1]; b2 = o[2]; b3 = o[3];
+        }
+        uint32_t w = b0;
+        b0 = b1; b1 = b2; b2 = b3;
+        ++k;
+        return w;
+    }
+    PT_DEV float f32() { return (float)(word() >> 8) * 5.9604644775390625e-8f; }
+    PT_DEV double f64()
+    {
+        uint64_t hi = word(), lo = word();
+        return (double)(((hi << 32) | lo) >> 11) * 1.1102230246251565404e-16;
+    }
+    PT_DEV bool overrun() const { return false; }
+};
+
+// Explicit uniforms for the parity probes.
+struct TapeRng
+{
+    const float* t32; const double* t64; uint32_t n32, n64, i32, i64; bool over;
+    PT_DEV void init(const float* a, uint32_t na, const double* b, uint32_t nb) { t32 = a; n32 = na; t64 = b; n64 = nb; i32 = i64 = 0; over = false; }
+    PT_DEV float f32() { if (i32 >= n32) { over = true; ++i32; return 0.5f; } return t32[i32++]; }
+    PT_DEV double f64() { if (i64 >= n64) { over = true; ++i64; return 0.5; } return t64[i64++]; }
+    PT_DEV bool overrun() const { return over; }
+};
+
+template <class R> PT_DEV float rand_range(R& r, float lo, float hi) { return r.f32() * (hi - lo) + lo; } // utils.h:47-51
+
+// ------------------------------------------------------------------ samplers (utils.h:71-138)
+// Draw order z,y,x / y,x: what g++ makes of the reference's unspecified argument order.
+template <class R> PT_DEV V3 random_point_in_unit_sphere(R& r)               // utils.h:80-94
+{
+    V3 p;
+    for (;;)
+    {
+        float z = rand_range(r, -1.0f, 1.0f), y = rand_range(r, -1.0f, 1.0f), x = rand_range(r, -1.0f, 1.0f);
+        p = v3(x, y, z);
+        if (norm(p) <= 1.0f) break;
+    }
+    return p;
+}
+template <class R> PT_DEV V3 random_unit_vector(R& r) { return normalize(random_point_in_unit_sphere(r)); } // utils.h:102-108
+template <class R> PT_DEV V3 random_point_in_unit_circle(R& r)               // utils.h:124-138
+{
+    V3 p;
+    for (;;)
+    {
+        float y = rand_range(r, -1.0f, 1.0f), x = rand_range(r, -1.0f, 1.0f);
+        p = v3(x, y, 0.0f);
+        if (norm(p) <= 1.0f) break;
+    }
+    return p;
+}
+
+// ------------------------------------------------------------------ camera (camera.cpp:57-79)
+// Everything that does not depend on (u,v) is folded on the host in the same f32 operation order
+// (pt_host.cpp: make_device_camera), so the per-ray part below continues the reference's expression trees.
+struct DeviceCamera
+{
+    float pos[3], horizontal[3], vertical[3], topLeft[3];
+    float planeW, planeH, focus, lensRadius;
+};
+template <class R> PT_DEV Ray get_ray(const DeviceCamera& c, float u, float v, R& rng)
+{
+    V3 pos = v3(c.pos[0], c.pos[1], c.pos[2]);
+    V3 horizontal = v3(c.horizontal[0], c.horizontal[1], c.horizontal[2]);
+    V3 vertical = v3(c.vertical[0], c.vertical[1], c.vertical[2]);
+    V3 topLeft = v3(c.topLeft[0], c.topLeft[1], c.topLeft[2]);
+    V3 rayTarget = sub(add(topLeft, mul(mul(mul(horizontal, u), c.planeW), c.focus)),
+                       mul(mul(mul(vertical, v), c.planeH), c.focus));                        // camera.cpp:70
+    V3 pointOnLens = mul(random_point_in_unit_circle(rng), c.lensRadius);                      // camera.cpp:74
+    V3 lensOffset = add(mul(horizontal, pointOnLens.x), mul(vertical, pointOnLens.y));         // camera.cpp:75
+    Ray r;
+    r.o = add(pos, lensOffset);
+    r.d = normalize(sub(rayTarget, add(pos, lensOffset)));                                     // camera.cpp:77
+    return r;
+}
+
+// ------------------------------------------------------------------ scene view (LDS-resident blob)
+// Blob = array of float4, identical in HBM and LDS (pt_host.cpp: build_blob):
+//   pairs   [2*npairs] : A = {cx0,cx1,cy0,cy1}  B = {cz0,cz1,r2_0,r2_1}     (two spheres per entry, SoA-of-pairs)
+//   velp    [2*npairs] : A = {vx0,vx1,vy0,vy1}  B = {vz0,vz1,0,0}           (only if the scene moves)
+//   smat    [2*ns]     : {type bits, roughness, n, 0}, {r,g,b,a}
+//   planes  [np]       : {nx,ny,nz,offset}
+//   pmat    [2*np]     : as smat
+struct SceneView
+{
+    const float4* pairs; const float4* velp; const float4* smat; const float4* planes; const float4* pmat;
+    uint32_t ns, npairs, np; uint32_t idx_mask; // idx_mask = 2^bits-1 >= 2*npairs-1
+};
+
+struct Material { uint32_t type; V4 colour; float roughness, n; };
+PT_DEV Material load_material(const float4* m, uint32_t i)
+{
+    float4 a = m[2 * i], b = m[2 * i + 1];
+    Material r; r.type = __float_as_uint(a.x); r.roughness = a.y; r.n = a.z; r.colour = v4(b.x, b.y, b.z, b.w);
+    return r;
+}
+
+PT_DEV void load_sphere(const SceneView& s, uint32_t i, V3* c, float* r2)
+{
+    const float* p = reinterpret_cast<const float*>(s.pairs + 2 * (i >> 1));
+    uint32_t l = i & 1u;
+    *c = v3(p[l], p[2 + l], p[4 + l]);
+    *r2 = p[6 + l];
+}
+PT_DEV V3 load_velocity(const SceneView& s, uint32_t i)
+{
+    const float* p = reinterpret_cast<const float*>(s.velp + 2 * (i >> 1));
+    uint32_t l = i & 1u;
+    return v3(p[l], p[2 + l], p[4 + l]);
+}
+
+// intersection_test(Ray, Sphere) in the reference's arithmetic (geometry.cpp:39-68); r2 = radius*radius.
+PT_DEV float intersect_sphere_exact(const Ray& ray, V3 centre, float r2)
+{
+    float tResult = kF32Max;
+    V3 oc = sub(ray.o, centre);
+    float b = 2 * dot(ray.d, oc);
+    float c = dot(oc, oc) - r2;
+    float discriminant = b * b - 4 * c;
+    if (discriminant > 0)
+    {
+        float rootValue = sqrtf(discriminant);
+        tResult = (-b - rootValue) / 2;
+    }
+    else if (discriminant == 0)
+        tResult = -b / 2;
+    return tResult;
+}
+// intersection_test(Ray, Plane) (geometry.cpp:70-81)
+PT_DEV float intersect_plane_exact(const Ray& ray, V3 n, float offset)
+{
+    float tResult = kF32Max;
+    float denominator = dot(ray.d, n);
+    if (denominator != 0.0f) tResult = (offset - dot(n, ray.o)) / denominator;
+    return tResult;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The search: smallest t > kMinT over all spheres, returned as the sphere index (or -1).
+// Key trick: w = t - kMinT as raw bits with the sphere index spliced into the low mantissa bits; valid hits are
+// positive floats, which order like unsigned integers; negative w (behind / self hit) has the sign bit set and
+// NaN (no real root) is above +inf, so ONE unsigned min3 per sphere pair does validity test, closest test and
+// index tracking.  Resolution of the ordering: 2^-(23-bits) relative (bits <= 10 -> 1.2e-4), which only matters
+// for two different spheres hit at distances that close (interpenetrating spheres' seam).
+template <bool MOVING> PT_DEV int32_t search_spheres_fast(const SceneView& s, const Ray& ray, float time)
+{
+#pragma clang fp contract(fast)
+    // Origin advanced by kMinT along the (unit) direction: the near root measured from there IS t - kMinT.
+    const float sx = ray.o.x + kMinT * ray.d.x, sy = ray.o.y + kMinT * ray.d.y, sz = ray.o.z + kMinT * ray.d.z;
+    const f32x2 ox = {sx, sx}, oy = {sy, sy}, oz = {sz, sz};
+    const f32x2 dx = {ray.d.x, ray.d.x}, dy = {ray.d.y, ray.d.y}, dz = {ray.d.z, ray.d.z};
+    const f32x2 tt = {time, time};
+    const uint32_t keep = ~s.idx_mask;
+    uint32_t best = 0x7F800000u; // +inf
+    const uint32_t np = s.npairs;
+#pragma unroll 4
+    for (uint32_t j = 0; j < np; ++j)
+    {
+        float4 A = s.pairs[2 * j], B = s.pairs[2 * j + 1];
+        f32x2 cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, r2 = {B.z, B.w};
+        if (MOVING)
+        {
+            float4 VA = s.velp[2 * j], VB = s.velp[2 * j + 1];
+            f32x2 vx = {VA.x, VA.y}, vy = {VA.z, VA.w}, vz = {VB.x, VB.y};
+            cx = vx * tt + cx; cy = vy * tt + cy; cz = vz * tt + cz; // main.cpp:66
+        }
+        f32x2 ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+        f32x2 hb = ocx * dx + ocy * dy + ocz * dz;                      // b/2
+        f32x2 c = ocx * ocx + (ocy * ocy + (ocz * ocz - r2));
+        f32x2 disc = hb * hb - c;                                       // discriminant/4
+        float w0 = -hb.x - __builtin_amdgcn_sqrtf(disc.x);              // t - kMinT; NaN when disc < 0
+        float w1 = -hb.y - __builtin_amdgcn_sqrtf(disc.y);
+        uint32_t k0 = (__float_as_uint(w0) & keep) | (2 * j);
+        uint32_t k1 = (__float_as_uint(w1) & keep) | (2 * j + 1);
+        best = min(best, min(k0, k1));
+    }
+    return best < 0x7F800000u ? (int32_t)(best & s.idx_mask) : -1;
+}
+
+// The same query in reference arithmetic for EVERY sphere: lowest index wins ties (oracle: query_closest).
+template <bool MOVING> PT_DEV int32_t search_spheres_strict(const SceneView& s, const Ray& ray, float time, float* tOut)
+{
+    float best = kF32Max;
+    int32_t obj = -1;
+    for (uint32_t i = 0; i < s.ns; ++i)
+    {
+        V3 c; float r2;
+        load_sphere(s, i, &c, &r2);
+        if (MOVING) c = add(c, mul(load_velocity(s, i), time));
+        float t = intersect_sphere_exact(ray, c, r2);
+        if (t > kMinT && t < best) { best = t; obj = (int32_t)i; }
+    }
+    *tOut = best;
+    return obj;
+}
+
+struct Hit { float t; int32_t prim; V3 point, normal; Material m; };
+
+// First half of cast_ray (main.cpp:180-216): planes linearly, then the sphere query; closest wins, planes win ties.
+template <bool MOVING, bool STRICT> PT_DEV Hit closest_hit(const SceneView& s, const Ray& ray, float time)
+{
+    Hit h;
+    h.t = kF32Max; h.prim = kPrimMiss; h.point = v3(0, 0, 0); h.normal = v3(0, 0, 0);
+    h.m.type = MAT_NONE; h.m.colour = v4(0, 0, 0, 0); h.m.roughness = 0; h.m.n = 0;
+    int32_t planeIdx = -1;
+    for (uint32_t i = 0; i < s.np; ++i)                                  // main.cpp:186-200
+    {
+        float4 p = s.planes[i];
+        float t = intersect_plane_exact(ray, v3(p.x, p.y, p.z), p.w);
+        if (t > kMinT && t < h.t) { h.t = t; planeIdx = (int32_t)i; }
+    }
+    int32_t obj;
+    float t = kF32Max;
+    V3 centre = v3(0, 0, 0);
+    if (STRICT)
+    {
+        obj = search_spheres_strict<MOVING>(s, ray, time, &t);
+        if (obj >= 0)
+        {
+            float r2; load_sphere(s, (uint32_t)obj, &centre, &r2);
+            if (MOVING) centre = add(centre, mul(load_velocity(s, (uint32_t)obj), time));
+        }
+    }
+    else
+    {
+        obj = search_spheres_fast<MOVING>(s, ray, time);
+        if (obj >= 0) // the winner's t, re-evaluated in reference arithmetic
+        {
+            float r2; load_sphere(s, (uint32_t)obj, &centre, &r2);
+            if (MOVING) centre = add(centre, mul(load_velocity(s, (uint32_t)obj), time));
+            t = intersect_sphere_exact(ray, centre, r2);
+        }
+    }
+    if (obj >= 0 && t > kMinT && t < h.t)                                // main.cpp:204-216
+    {
+        h.t = t; h.prim = obj;
+        h.point = ray_at(ray, t);
+        h.normal = normalize(sub(h.point, centre));
+        h.m = load_material(s.smat, (uint32_t)obj);
+    }
+    else if (planeIdx >= 0)
+    {
+        float4 p = s.planes[planeIdx];
+        h.prim = -1 - planeIdx;
+        h.point = ray_at(ray, h.t);
+        h.normal = v3(p.x, p.y, p.z);
+        h.m = load_material(s.pmat, (uint32_t)planeIdx);
+    }
+    return h;
+}
+
+// reflectance (main.cpp:161-168): the reference's f64 island.  pow(x,5) is evaluated as x*x*x*x*x here; it feeds
+// only the comparison against a 53-bit uniform, so a last-bit difference flips a decision with probability ~1e-16.
+PT_DEV double reflectance(double cosine, double refractRatio)
+{
+    double r0 = (1.0 - refractRatio) / (1.0 + refractRatio);
+    r0 = r0 * r0;
+    double x = 1.0 - cosine, x2 = x * x;
+    return r0 + (1.0 - r0) * (x2 * x2 * x);
+}
+
+// Second half of cast_ray (main.cpp:219-298).  Returns false when the path ends at this hit.
+template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray* out, uint32_t* event)
+{
+    *event = EV_SCATTER;
+    out->o = h.point;
+    if (h.m.type == MAT_DIFFUSE)                                         // main.cpp:223-234
+    {
+        V3 scatterDirection = add(random_unit_vector(rng), h.normal);
+        if (near_zero(add(scatterDirection, h.normal))) scatterDirection = h.normal; // sic (main.cpp:226)
+        out->d = normalize(scatterDirection);
+        return true;
+    }
+    if (h.m.type == MAT_METAL)                                           // main.cpp:235-259
+    {
+        V3 reflectedDir = reflect_direction(ray.d, h.normal);
+        if (h.m.roughness > 0.0f)
+        {
+            V3 centre = add(h.point, reflectedDir);
+            V3 randomPoint = add(mul(random_point_in_unit_sphere(rng), h.m.roughness), centre); // utils.h:96-100
+            reflectedDir = sub(randomPoint, h.point);
+        }
+        out->d = normalize(reflectedDir);
+        if (dot(reflectedDir, h.normal) > 0) return true;
+        *event = EV_ABSORB;
+        return false;
+    }
+    if (h.m.type == MAT_DIALECTRIC)                                      // main.cpp:260-297
+    {
+        float refractRatio = 1.0f / h.m.n;
+        if (dot(ray.d, h.normal) > 0.0f) refractRatio = 1.0f / refractRatio;
+        float cosTheta = dot(neg(ray.d), h.normal);
+        float sinTheta = sqrtf(1 - cosTheta * cosTheta);
+        bool internalReflection = refractRatio * sinTheta > 1.0f;
+        bool shouldReflect = reflectance((double)cosTheta, (double)refractRatio) > rng.f64();
+        V3 newRayDir;
+        if (internalReflection || shouldReflect)
+            newRayDir = reflect_direction(ray.d, h.normal);
+        else
+        {
+            V3 rayPerpendicular = mul(add(ray.d, mul(h.normal, cosTheta)), refractRatio);
+            float d = 1 - norm_squared(rayPerpendicular);
+            float ad = d < 0 ? -d : d;
+            V3 rayParallel = mul(h.normal, -sqrtf(ad));
+            newRayDir = add(rayPerpendicular, rayParallel);
+        }
+        out->d = normalize(newRayDir);
+        return true;
+    }
+    *event = EV_NONE_MAT;
+    out->d = v3(0, 0, 0);
+    return false;
+}
+
+PT_DEV V4 sky(const Ray& ray)                                            // main.cpp:299-304
+{
+    float ratio = 0.5f * (ray.d.y + 1.0f);
+    float a = 1.0f - ratio;
+    return v4(1.0f * a + 0.7f * ratio, 1.0f * a + 0.8f * ratio, 1.0f * a + 0.9f * ratio, 1.0f * a + 1.0f * ratio);
+}
+
+// One loop iteration of cast_ray.  Returns true while the path lives; when it ends, *terminal is the colour the
+// throughput must be multiplied with (sky, BLACK (0,0,0,1), or (0,0,0,0) for a NONE material).
+template <class R>
+PT_DEV bool shade_step(Ray& ray, const Hit& h, V4& throughput, R& rng, V4* terminal)
+{
+    if (h.t != kF32Max && h.t > 0)                                       // main.cpp:219
+    {
+        Ray next; uint32_t ev;
+        bool alive = scatter(ray, h, rng, &next, &ev);
+        if (!alive)
+        {
+            *terminal = (ev == EV_ABSORB) ? v4(0, 0, 0, 1) : v4(0, 0, 0, 0);
+            return false;
+        }
+        throughput = hadamard(throughput, h.m.colour);                   // main.cpp:233,255,296 (loop form)
+        ray = next;
+        return true;
+    }
+    *terminal = sky(ray);
+    return false;
+}
+template <bool MOVING, bool STRICT, class R>
+PT_DEV bool path_step(const SceneView& s, Ray& ray, float time, V4& throughput, R& rng, V4* terminal)
+{
+    const Hit h = closest_hit<MOVING, STRICT>(s, ray, time);
+    return shade_step(ray, h, throughput, rng, terminal);
+}
+
+// cast_ray (main.cpp:171-307) as a loop, for the probes.
+template <bool MOVING, bool STRICT, class R>
+PT_DEV V4 cast_ray(const SceneView& s, Ray ray, uint32_t maxDepth, float time, R& rng, uint32_t* segments)
+{
+    V4 T = v4(1, 1, 1, 1), terminal = v4(0, 0, 0, 1);
+    uint32_t n = 0;
+    for (uint32_t depth = maxDepth; depth != 0; --depth)                 // depth 0 -> BLACK (main.cpp:175-176)
+    {
+        ++n;
+        if (!path_step<MOVING, STRICT>(s, ray, time, T, rng, &terminal)) break;
+        terminal = v4(0, 0, 0, 1);
+    }
+    *segments = n;
+    return hadamard(T, terminal);
+}
+
+// The head of one sample (main.cpp:349-354): time, jittered (u,v), primary ray.
+template <class R>
+PT_DEV Ray begin_sample(const DeviceCamera& cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h, float t0, float t1, R& rng, float* time)
+{
+    *time = rand_range(rng, t0, t1);                                     // main.cpp:349
+    float u = ((float)px + rng.f32()) / (float)w;                        // main.cpp:351
+    float v = ((float)py - rng.f32()) / (float)h;                        // main.cpp:352
+    return get_ray(cam, u, v, rng);                                      // main.cpp:354
+}
+
+} // namespace ptd

@@ -1,0 +1,703 @@
+// pt_hip.hip -- kernels and C-ABI of libpt_hip.so (gfx950 only; see include/pt_hip.h for the boundary).
+//
+// Kernels
+//   k_render_lds<MOVING,STRICT>  the hot path: one wave = one 8x8 pixel tile x all samples of the call; lanes pull
+//                                (pixel, sample) work items from a wave-local pool so that a lane whose path ended
+//                                starts its next sample in the same iteration (path regeneration); the scene is
+//                                staged once per workgroup into LDS and searched by brute force.
+//   k_probe_*                    the same device functions on caller-supplied records (parity harness).
+//   k_resolve                    clamp(mean) + gamma-2 + 8-bit BGRA pack.
+// Host code below the kernels implements include/pt_hip.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <cmath>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_hip.h"
+#include "pt_device.h"
+#include "pt_host.h"
+
+using namespace ptd;
+
+// ================================================================================================ kernel arguments
+struct SceneArgs
+{
+    const float4* blob; // HBM copy of the LDS image
+    uint32_t blob_f4;   // its length in float4
+    uint32_t off_velp, off_smat, off_planes, off_pmat;
+    uint32_t ns, npairs, np, idx_mask;
+    float t0, t1;
+    DeviceCamera cam;
+};
+
+__device__ __forceinline__ SceneView make_view(const float4* base, const SceneArgs& a)
+{
+    SceneView s;
+    s.pairs = base; s.velp = base + a.off_velp; s.smat = base + a.off_smat; s.planes = base + a.off_planes; s.pmat = base + a.off_pmat;
+    s.ns = a.ns; s.npairs = a.npairs; s.np = a.np; s.idx_mask = a.idx_mask;
+    return s;
+}
+
+__device__ __forceinline__ void stage_scene(float4* smem, const SceneArgs& a)
+{
+    for (uint32_t i = threadIdx.x; i < a.blob_f4; i += blockDim.x) smem[i] = a.blob[i];
+}
+
+struct RenderArgs
+{
+    SceneArgs sc;
+    uint32_t width, height, tiles_x, ntiles, tile_stride;
+    uint32_t spp_begin, nspp, max_depth;
+    uint64_t seed;
+    float* out_sum;                 // width*height*4
+    unsigned long long* stats;      // [0] segments
+};
+
+constexpr uint32_t kWavesPerBlock = 4;
+
+// ================================================================================================ the hot kernel
+template <bool MOVING, bool STRICT>
+__global__ void __launch_bounds__(256) k_render_lds(RenderArgs a)
+{
+    extern __shared__ float4 smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    stage_scene(smem, a.sc);
+    float* acc = reinterpret_cast<float*>(smem + a.sc.blob_f4) + wave * 256u; // [64 pixels][rgba] of this wave's tile
+    acc[lane] = 0.0f; acc[lane + 64] = 0.0f; acc[lane + 128] = 0.0f; acc[lane + 192] = 0.0f;
+    __syncthreads();
+
+    const uint32_t slot = blockIdx.x * kWavesPerBlock + wave;
+    if (slot >= a.ntiles) return;
+    // Neighbouring tiles cost alike (sky rows are cheap, the sphere field is not): a multiplicative shuffle of the
+    // tile order mixes cheap and expensive tiles over the whole launch, so the tail is one tile, not one region.
+    const uint32_t tile = (uint32_t)(((unsigned long long)slot * a.tile_stride) % a.ntiles);
+    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const SceneView s = make_view(smem, a.sc);
+
+    const uint32_t total = 64u * a.nspp; // work items of this wave: item i = (pixel i&63 of the tile, sample i>>6)
+    uint32_t next = 0;                   // wave-uniform cursor into the pool
+    bool alive = false, retired = false;
+    // The live ray is kept as six scalars: as a struct it stays an un-promoted alloca (scratch traffic in the loop).
+    float rox = 0, roy = 0, roz = 0, rdx = 0, rdy = 0, rdz = 1;
+    V4 T = v4(1, 1, 1, 1);
+    float time = 0.0f;
+    uint32_t depth = 0, p = 0;
+    PhiloxRng rng; rng.init(a.seed, 0, 0);
+    uint32_t segs = 0;
+
+    for (;;)
+    {
+        // ---- refill: every lane without a live path takes the next work item (main.cpp:347-354)
+        const bool want = !alive && !retired;
+        const unsigned long long need = __ballot(want);
+        if (need)
+        {
+            if (want)
+            {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                const uint32_t item = next + rank;
+                if (item < total)
+                {
+                    p = item & 63u;
+                    const uint32_t px = tx * 8u + (p & 7u), py = ty * 8u + (p >> 3);
+                    if (px < a.width && py < a.height) // ragged edge tiles: the item is skipped
+                    {
+                        rng.init(a.seed, py * a.width + px, a.spp_begin + (item >> 6));
+                        const Ray r0 = begin_sample(a.sc.cam, px, py, a.width, a.height, a.sc.t0, a.sc.t1, rng, &time);
+                        rox = r0.o.x; roy = r0.o.y; roz = r0.o.z; rdx = r0.d.x; rdy = r0.d.y; rdz = r0.d.z;
+                        T = v4(1, 1, 1, 1);
+                        depth = a.max_depth;
+                        alive = depth != 0;
+                        if (!alive) atomicAdd(&acc[p * 4u + 3u], 1.0f); // maxDepth 0 -> BLACK (0,0,0,1) (main.cpp:175-176)
+                    }
+                }
+                else
+                    retired = true;
+            }
+            next += (uint32_t)__popcll(need);
+        }
+        if (__ballot(alive) == 0ull)
+        {
+            if (next >= total) break;
+            continue;
+        }
+        // ---- one segment for every lane (lanes without a live path ride along on stale data)
+        Ray ray; ray.o = v3(rox, roy, roz); ray.d = v3(rdx, rdy, rdz);
+        const Hit h = closest_hit<MOVING, STRICT>(s, ray, time);
+        if (alive)
+        {
+            ++segs;
+            V4 terminal;
+            const bool goes_on = shade_step(ray, h, T, rng, &terminal);
+            rox = ray.o.x; roy = ray.o.y; roz = ray.o.z; rdx = ray.d.x; rdy = ray.d.y; rdz = ray.d.z;
+            bool ended = !goes_on;
+            if (goes_on && --depth == 0) { terminal = v4(0, 0, 0, 1); ended = true; } // main.cpp:175-176
+            if (ended)
+            {
+                const V4 c = hadamard(T, terminal);
+                atomicAdd(&acc[p * 4u + 0u], c.x); atomicAdd(&acc[p * 4u + 1u], c.y);
+                atomicAdd(&acc[p * 4u + 2u], c.z); atomicAdd(&acc[p * 4u + 3u], c.w);
+                alive = false;
+            }
+        }
+    }
+
+    // ---- one 16-byte store per pixel: the only HBM traffic of the render besides staging the scene
+    {
+        const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
+        if (px < a.width && py < a.height)
+        {
+            float4 v = make_float4(acc[lane * 4u], acc[lane * 4u + 1u], acc[lane * 4u + 2u], acc[lane * 4u + 3u]);
+            reinterpret_cast<float4*>(a.out_sum)[(size_t)py * a.width + px] = v;
+        }
+    }
+    // ---- statistics: segments of this wave
+    for (int o = 32; o > 0; o >>= 1) segs += __shfl_xor(segs, o);
+    if (lane == 0) atomicAdd(a.stats, (unsigned long long)segs);
+}
+
+// ================================================================================================ probes
+struct ProbeHitsArgs { SceneArgs sc; uint32_t n; const float* rays; const float* times; float* t; int32_t* prim; float* point; float* normal; };
+template <bool MOVING, bool STRICT> __global__ void __launch_bounds__(256) k_probe_hits(ProbeHitsArgs a)
+{
+    extern __shared__ float4 smem[];
+    stage_scene(smem, a.sc);
+    __syncthreads();
+    const SceneView s = make_view(smem, a.sc);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    Ray r; r.o = v3(a.rays[6*i], a.rays[6*i+1], a.rays[6*i+2]); r.d = v3(a.rays[6*i+3], a.rays[6*i+4], a.rays[6*i+5]);
+    Hit h = closest_hit<MOVING, STRICT>(s, r, a.times[i]);
+    a.t[i] = h.t; a.prim[i] = h.prim;
+    a.point[3*i] = h.point.x; a.point[3*i+1] = h.point.y; a.point[3*i+2] = h.point.z;
+    a.normal[3*i] = h.normal.x; a.normal[3*i+1] = h.normal.y; a.normal[3*i+2] = h.normal.z;
+}
+
+struct ProbeRaysArgs { DeviceCamera cam; uint32_t n; const float* uv; const float* tape; const unsigned long long* ofs; float* rays; };
+__global__ void __launch_bounds__(256) k_probe_get_rays(ProbeRaysArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    TapeRng rng; rng.init(a.tape + a.ofs[i], (uint32_t)(a.ofs[i+1] - a.ofs[i]), nullptr, 0);
+    Ray r = get_ray(a.cam, a.uv[2*i], a.uv[2*i+1], rng);
+    float* o = a.rays + 6 * (size_t)i;
+    o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+}
+
+struct ProbeScatterArgs
+{
+    uint32_t n; const float* dirs; const float* points; const float* normals; const uint32_t* type; const float* rgba; const float* param;
+    const float* tape32; const unsigned long long* ofs32; const double* tape64; const unsigned long long* ofs64; float* out_dir; uint32_t* out_event;
+};
+__global__ void __launch_bounds__(256) k_probe_scatter(ProbeScatterArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    Ray r; r.o = v3(0, 0, 0); r.d = v3(a.dirs[3*i], a.dirs[3*i+1], a.dirs[3*i+2]);
+    Hit h; h.t = 1.0f; h.prim = 0;
+    h.point = v3(a.points[3*i], a.points[3*i+1], a.points[3*i+2]); h.normal = v3(a.normals[3*i], a.normals[3*i+1], a.normals[3*i+2]);
+    h.m.type = a.type[i]; h.m.colour = v4(a.rgba[4*i], a.rgba[4*i+1], a.rgba[4*i+2], a.rgba[4*i+3]); h.m.roughness = a.param[2*i]; h.m.n = a.param[2*i+1];
+    TapeRng rng; rng.init(a.tape32 + a.ofs32[i], (uint32_t)(a.ofs32[i+1] - a.ofs32[i]), a.tape64 + a.ofs64[i], (uint32_t)(a.ofs64[i+1] - a.ofs64[i]));
+    Ray next; next.o = v3(0, 0, 0); next.d = v3(0, 0, 0); uint32_t ev;
+    scatter(r, h, rng, &next, &ev);
+    a.out_dir[3*i] = next.d.x; a.out_dir[3*i+1] = next.d.y; a.out_dir[3*i+2] = next.d.z;
+    a.out_event[i] = ev | (rng.overrun() ? 0x80000000u : 0u);
+}
+
+struct ProbePathsArgs
+{
+    SceneArgs sc; uint32_t n, max_depth; const float* rays; const float* times;
+    const float* tape32; const unsigned long long* ofs32; const double* tape64; const unsigned long long* ofs64; float* rgba; uint32_t* segs;
+};
+template <bool MOVING, bool STRICT> __global__ void __launch_bounds__(256) k_probe_paths(ProbePathsArgs a)
+{
+    extern __shared__ float4 smem[];
+    stage_scene(smem, a.sc);
+    __syncthreads();
+    const SceneView s = make_view(smem, a.sc);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    Ray r; r.o = v3(a.rays[6*i], a.rays[6*i+1], a.rays[6*i+2]); r.d = v3(a.rays[6*i+3], a.rays[6*i+4], a.rays[6*i+5]);
+    TapeRng rng; rng.init(a.tape32 + a.ofs32[i], (uint32_t)(a.ofs32[i+1] - a.ofs32[i]), a.tape64 + a.ofs64[i], (uint32_t)(a.ofs64[i+1] - a.ofs64[i]));
+    uint32_t n = 0;
+    V4 c = cast_ray<MOVING, STRICT>(s, r, a.max_depth, a.times[i], rng, &n);
+    a.rgba[4*i] = c.x; a.rgba[4*i+1] = c.y; a.rgba[4*i+2] = c.z; a.rgba[4*i+3] = c.w;
+    if (a.segs) a.segs[i] = n | (rng.overrun() ? 0x80000000u : 0u);
+}
+
+struct ProbeSamplesArgs { SceneArgs sc; uint32_t n, width, height, max_depth; uint64_t seed; const uint32_t* pixels; const uint32_t* samples; float* rgba; uint32_t* segs; };
+template <bool MOVING, bool STRICT> __global__ void __launch_bounds__(256) k_probe_samples(ProbeSamplesArgs a)
+{
+    extern __shared__ float4 smem[];
+    stage_scene(smem, a.sc);
+    __syncthreads();
+    const SceneView s = make_view(smem, a.sc);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t pixel = a.pixels[i];
+    PhiloxRng rng; rng.init(a.seed, pixel, a.samples[i]);
+    float time;
+    Ray r = begin_sample(a.sc.cam, pixel % a.width, pixel / a.width, a.width, a.height, a.sc.t0, a.sc.t1, rng, &time);
+    uint32_t n = 0;
+    V4 c = cast_ray<MOVING, STRICT>(s, r, a.max_depth, time, rng, &n);
+    a.rgba[4*i] = c.x; a.rgba[4*i+1] = c.y; a.rgba[4*i+2] = c.z; a.rgba[4*i+3] = c.w;
+    if (a.segs) a.segs[i] = n;
+}
+
+__global__ void k_probe_philox(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    PhiloxRng rng; rng.init(seed, pixel, sample);
+    for (uint32_t i = 0; i < n; ++i) out[i] = rng.word();
+}
+
+// ================================================================================================ resolve
+// main.cpp:358 (mean, clamp) and file_io.h:29-45 (gamma 2, truncating quantise, 0xAARRGGBB).
+__device__ __forceinline__ float clamp01(float v) { if (v < 0.0f) return 0.0f; else if (v > 1.0f) return 1.0f; return v; } // utils.h:8-15
+__global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ sum, uint32_t n, float inv_spp, float4* __restrict__ pixels, uint32_t* __restrict__ bgra)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        float4 v = sum[i];
+        v.x = clamp01(v.x * inv_spp); v.y = clamp01(v.y * inv_spp); v.z = clamp01(v.z * inv_spp); v.w = clamp01(v.w * inv_spp);
+        if (pixels) pixels[i] = v;
+        if (bgra)
+        {
+            uint32_t r = (uint8_t)(255.0f * sqrtf(v.x)), g = (uint8_t)(255.0f * sqrtf(v.y)), b = (uint8_t)(255.0f * sqrtf(v.z)), al = (uint8_t)(255.0f * sqrtf(v.w));
+            bgra[i] = (al << 24) | (r << 16) | (g << 8) | b;
+        }
+    }
+}
+
+// ================================================================================================ host side
+struct pt_ctx
+{
+    int device = -1;
+    std::string err;
+    pth::Blob blob;          // host image of the scene blob + offsets
+    bool has_scene = false;
+    float4* blob_dev = nullptr;
+    SceneArgs sc{};
+    float* accum_dev = nullptr; size_t accum_floats = 0;
+    unsigned long long* stats_dev = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    pt_stats last{};
+    size_t lds_limit = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                                       \
+    do {                                                                                                        \
+        hipError_t e_ = (call);                                                                                 \
+        if (e_ != hipSuccess) {                                                                                 \
+            if (ctx) (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+            return PT_ERR_HIP;                                                                                  \
+        }                                                                                                       \
+    } while (0)
+
+struct Bind // make the context's device current for the duration of a call
+{
+    int prev = -1; bool ok = false;
+    explicit Bind(pt_ctx* c) { if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(c->device) == hipSuccess) ok = true; }
+    ~Bind() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+constexpr size_t kMaxLdsBytes = 128 * 1024; // of the 160 KiB per CU; leaves room for a second workgroup on small scenes
+
+size_t lds_bytes_render(const SceneArgs& sc) { return (size_t)sc.blob_f4 * 16 + kWavesPerBlock * 64 * 16; }
+size_t lds_bytes_probe(const SceneArgs& sc) { return (size_t)sc.blob_f4 * 16; }
+
+uint32_t pick_stride(uint32_t ntiles)
+{
+    // a multiplier coprime to ntiles, near the golden ratio of it
+    if (ntiles < 3) return 1;
+    auto gcd = [](uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; };
+    uint32_t s = (uint32_t)((double)ntiles * 0.6180339887498949);
+    if (s < 1) s = 1;
+    while (gcd(s, ntiles) != 1) ++s;
+    return s;
+}
+
+template <class K> int set_lds(pt_ctx* ctx, K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024)
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PT_OK;
+}
+
+int check_scene(pt_ctx* ctx)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->has_scene) return PT_ERR_NO_SCENE;
+    return PT_OK;
+}
+
+// device scratch that frees itself
+struct DevBuf
+{
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+} // namespace
+
+extern "C" {
+
+int pt_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* pt_hip_strerror(int status)
+{
+    switch (status)
+    {
+    case PT_OK: return "ok";
+    case PT_ERR_INVALID: return "invalid argument";
+    case PT_ERR_NO_DEVICE: return "no such HIP device";
+    case PT_ERR_HIP: return "HIP call failed (see pt_hip_last_error)";
+    case PT_ERR_NO_SCENE: return "no scene uploaded";
+    case PT_ERR_UNSUPPORTED: return "unsupported scene or flag combination";
+    case PT_ERR_IO: return "I/O error";
+    default: return "unknown status";
+    }
+}
+
+const char* pt_hip_last_error(pt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int pt_hip_create(int device, pt_ctx** out)
+{
+    if (!out) return PT_ERR_INVALID;
+    *out = nullptr;
+    int n = pt_hip_device_count();
+    if (device < 0 || device >= n) return PT_ERR_NO_DEVICE;
+    pt_ctx* c = new (std::nothrow) pt_ctx();
+    if (!c) return PT_ERR_INVALID;
+    c->device = device;
+    Bind b(c);
+    if (!b.ok) { delete c; return PT_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return PT_ERR_NO_DEVICE; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    {
+        // Written for CDNA4 only; refuse loudly rather than run an untested configuration.
+        fprintf(stderr, "pt_hip: device %d is %s, this library is built for gfx950 only\n", device, prop.gcnArchName);
+        delete c;
+        return PT_ERR_NO_DEVICE;
+    }
+    c->lds_limit = kMaxLdsBytes;
+    if (hipMalloc((void**)&c->stats_dev, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
+    {
+        pt_hip_destroy(c);
+        return PT_ERR_HIP;
+    }
+    *out = c;
+    return PT_OK;
+}
+
+void pt_hip_destroy(pt_ctx* c)
+{
+    if (!c) return;
+    Bind b(c);
+    if (c->blob_dev) (void)hipFree(c->blob_dev);
+    if (c->accum_dev) (void)hipFree(c->accum_dev);
+    if (c->stats_dev) (void)hipFree(c->stats_dev);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
+{
+    if (!ctx || !d) return PT_ERR_INVALID;
+    int st = pth::validate_desc(d);
+    if (st != PT_OK) return st;
+    Bind b(ctx);
+    pth::build_blob(d, &ctx->blob);
+    if (ctx->blob_dev) { (void)hipFree(ctx->blob_dev); ctx->blob_dev = nullptr; }
+    ctx->has_scene = false;
+    const size_t bytes = ctx->blob.f4.size() * sizeof(float4);
+    HIPCHK(ctx, hipMalloc((void**)&ctx->blob_dev, bytes ? bytes : 16));
+    HIPCHK(ctx, hipMemcpy(ctx->blob_dev, ctx->blob.f4.data(), bytes, hipMemcpyHostToDevice));
+    SceneArgs& sc = ctx->sc;
+    sc.blob = ctx->blob_dev; sc.blob_f4 = (uint32_t)ctx->blob.f4.size();
+    sc.off_velp = ctx->blob.off_velp; sc.off_smat = ctx->blob.off_smat; sc.off_planes = ctx->blob.off_planes; sc.off_pmat = ctx->blob.off_pmat;
+    sc.ns = d->n_spheres; sc.npairs = ctx->blob.npairs; sc.np = d->n_planes; sc.idx_mask = ctx->blob.idx_mask;
+    sc.t0 = d->t0; sc.t1 = d->t1;
+    pth::make_device_camera(d->camera, &sc.cam);
+    ctx->has_scene = true;
+    return PT_OK;
+}
+
+int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void* stream_)
+{
+    int st = check_scene(ctx);
+    if (st != PT_OK) return st;
+    if (!p || !accum_dev || p->width == 0 || p->height == 0 || p->spp_end <= p->spp_begin) return PT_ERR_INVALID;
+    if ((uint64_t)p->width * p->height > 0xFFFFFFFFull || (uint64_t)(p->spp_end - p->spp_begin) * 64ull > 0xFFFFFFFFull) return PT_ERR_INVALID;
+    if (p->flags & PT_FLAG_FORCE_BVH) return PT_ERR_UNSUPPORTED;
+    Bind b(ctx);
+    hipStream_t stream = (hipStream_t)stream_;
+    RenderArgs a{};
+    a.sc = ctx->sc;
+    a.width = p->width; a.height = p->height;
+    a.tiles_x = (p->width + 7) / 8;
+    a.ntiles = a.tiles_x * ((p->height + 7) / 8);
+    a.tile_stride = pick_stride(a.ntiles);
+    a.spp_begin = p->spp_begin; a.nspp = p->spp_end - p->spp_begin; a.max_depth = p->max_depth; a.seed = p->seed;
+    a.out_sum = accum_dev; a.stats = ctx->stats_dev;
+    const size_t lds = lds_bytes_render(a.sc);
+    if (lds > ctx->lds_limit) return PT_ERR_UNSUPPORTED; // BVH-in-HBM kernel: not in this build yet (scope)
+    const bool moving = ctx->blob.moving, strict = (p->flags & PT_FLAG_STRICT_SEARCH) != 0;
+    const dim3 grid((a.ntiles + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+    HIPCHK(ctx, hipMemsetAsync(ctx->stats_dev, 0, 8 * sizeof(unsigned long long), stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
+#define LAUNCH_RENDER(M, S)                                                              \
+    do {                                                                                 \
+        st = set_lds(ctx, k_render_lds<M, S>, lds);                                      \
+        if (st != PT_OK) return st;                                                      \
+        hipLaunchKernelGGL((k_render_lds<M, S>), grid, block, lds, stream, a);           \
+    } while (0)
+    if (moving) { if (strict) LAUNCH_RENDER(true, true); else LAUNCH_RENDER(true, false); }
+    else        { if (strict) LAUNCH_RENDER(false, true); else LAUNCH_RENDER(false, false); }
+#undef LAUNCH_RENDER
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
+    ctx->timed = true;
+    ctx->last = pt_stats{};
+    ctx->last.samples = (uint64_t)p->width * p->height * a.nspp;
+    ctx->last.kernel = 0;
+    return PT_OK;
+}
+
+int pt_hip_render(pt_ctx* ctx, const pt_params* p, float* accum_host)
+{
+    int st = check_scene(ctx);
+    if (st != PT_OK) return st;
+    if (!p || !accum_host || p->width == 0 || p->height == 0) return PT_ERR_INVALID;
+    Bind b(ctx);
+    const size_t floats = (size_t)p->width * p->height * 4;
+    if (floats > ctx->accum_floats)
+    {
+        if (ctx->accum_dev) { (void)hipFree(ctx->accum_dev); ctx->accum_dev = nullptr; ctx->accum_floats = 0; }
+        HIPCHK(ctx, hipMalloc((void**)&ctx->accum_dev, floats * sizeof(float)));
+        ctx->accum_floats = floats;
+    }
+    st = pt_hip_render_device(ctx, p, ctx->accum_dev, nullptr);
+    if (st != PT_OK) return st;
+    HIPCHK(ctx, hipMemcpy(accum_host, ctx->accum_dev, floats * sizeof(float), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out)
+{
+    if (!ctx || !out) return PT_ERR_INVALID;
+    if (!ctx->timed) return PT_ERR_NO_SCENE;
+    Bind b(ctx);
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.0f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    unsigned long long st[8];
+    HIPCHK(ctx, hipMemcpy(st, ctx->stats_dev, sizeof(st), hipMemcpyDeviceToHost));
+    ctx->last.kernel_ms = ms;
+    ctx->last.segments = st[0];
+    ctx->last.sphere_tests = st[0] * (uint64_t)ctx->sc.ns;
+    ctx->last.node_visits = 0;
+    *out = ctx->last;
+    return PT_OK;
+}
+
+int pt_hip_resolve_device(pt_ctx* ctx, const float* accum_dev, uint32_t n_pixels, uint32_t spp_total, float* pixels_dev, uint32_t* bgra_dev, void* stream_)
+{
+    if (!ctx || !accum_dev || n_pixels == 0 || spp_total == 0) return PT_ERR_INVALID;
+    Bind b(ctx);
+    const float inv = 1.0f / (float)spp_total; // vectors.cpp:100-103
+    uint32_t blocks = (n_pixels + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, reinterpret_cast<const float4*>(accum_dev), n_pixels, inv,
+                       reinterpret_cast<float4*>(pixels_dev), bgra_dev);
+    HIPCHK(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ probes
+int pt_hip_probe_hits(pt_ctx* ctx, uint32_t n, const float* rays, const float* times, uint32_t flags,
+                      float* out_t, int32_t* out_prim, float* out_point, float* out_normal)
+{
+    int st = check_scene(ctx);
+    if (st != PT_OK) return st;
+    if (!rays || !times || !out_t || !out_prim || !out_point || !out_normal) return PT_ERR_INVALID;
+    if (n == 0) return PT_OK;
+    Bind b(ctx);
+    const size_t lds = lds_bytes_probe(ctx->sc);
+    if (lds > ctx->lds_limit) return PT_ERR_UNSUPPORTED;
+    DevBuf dr, dt, ot, op, opt, on;
+    HIPCHK(ctx, dr.alloc(n * 24ull)); HIPCHK(ctx, dt.alloc(n * 4ull)); HIPCHK(ctx, ot.alloc(n * 4ull));
+    HIPCHK(ctx, op.alloc(n * 4ull)); HIPCHK(ctx, opt.alloc(n * 12ull)); HIPCHK(ctx, on.alloc(n * 12ull));
+    HIPCHK(ctx, hipMemcpy(dr.p, rays, n * 24ull, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(dt.p, times, n * 4ull, hipMemcpyHostToDevice));
+    ProbeHitsArgs a{ctx->sc, n, dr.as<float>(), dt.as<float>(), ot.as<float>(), op.as<int32_t>(), opt.as<float>(), on.as<float>()};
+    const dim3 grid((n + 255) / 256), block(256);
+    const bool moving = ctx->blob.moving, strict = (flags & PT_FLAG_STRICT_SEARCH) != 0;
+#define LAUNCH(M, S) do { st = set_lds(ctx, k_probe_hits<M, S>, lds); if (st != PT_OK) return st; hipLaunchKernelGGL((k_probe_hits<M, S>), grid, block, lds, 0, a); } while (0)
+    if (moving) { if (strict) LAUNCH(true, true); else LAUNCH(true, false); }
+    else        { if (strict) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(out_t, ot.p, n * 4ull, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out_prim, op.p, n * 4ull, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out_point, opt.p, n * 12ull, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out_normal, on.p, n * 12ull, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_hip_probe_get_rays(pt_ctx* ctx, uint32_t n, const float* uv, const float* tape, const uint64_t* ofs, float* out_rays)
+{
+    int st = check_scene(ctx);
+    if (st != PT_OK) return st;
+    if (!uv || !tape || !ofs || !out_rays) return PT_ERR_INVALID;
+    if (n == 0) return PT_OK;
+    Bind b(ctx);
+    const uint64_t ntape = ofs[n];
+    DevBuf duv, dtape, dofs, dout;
+    HIPCHK(ctx, duv.alloc(n * 8ull)); HIPCHK(ctx, dtape.alloc(ntape * 4ull)); HIPCHK(ctx, dofs.alloc((n + 1ull) * 8)); HIPCHK(ctx, dout.alloc(n * 24ull));
+    HIPCHK(ctx, hipMemcpy(duv.p, uv, n * 8ull, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(dtape.p, tape, ntape * 4ull, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(dofs.p, ofs, (n + 1ull) * 8, hipMemcpyHostToDevice));
+    ProbeRaysArgs a{ctx->sc.cam, n, duv.as<float>(), dtape.as<float>(), dofs.as<unsigned long long>(), dout.as<float>()};
+    hipLaunchKernelGGL(k_probe_get_rays, dim3((n + 255) / 256), dim3(256), 0, 0, a);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(out_rays, dout.p, n * 24ull, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_hip_probe_scatter(pt_ctx* ctx, uint32_t n, const float* dirs, const float* points, const float* normals,
+                         const uint32_t* mat_type, const float* mat_rgba, const float* mat_param,
+                         const float* tape32, const uint64_t* ofs32, const double* tape64, const uint64_t* ofs64,
+                         float* out_dir, uint32_t* out_event)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!dirs || !points || !normals || !mat_type || !mat_rgba || !mat_param || !tape32 || !ofs32 || !tape64 || !ofs64 || !out_dir || !out_event) return PT_ERR_INVALID;
+    if (n == 0) return PT_OK;
+    Bind b(ctx);
+    const uint64_t n32 = ofs32[n], n64 = ofs64[n];
+    DevBuf dd, dp, dn, dty, drg, dpa, dt32, do32, dt64, do64, od, oe;
+    HIPCHK(ctx, dd.alloc(n * 12ull)); HIPCHK(ctx, dp.alloc(n * 12ull)); HIPCHK(ctx, dn.alloc(n * 12ull));
+    HIPCHK(ctx, dty.alloc(n * 4ull)); HIPCHK(ctx, drg.alloc(n * 16ull)); HIPCHK(ctx, dpa.alloc(n * 8ull));
+    HIPCHK(ctx, dt32.alloc(n32 * 4)); HIPCHK(ctx, do32.alloc((n + 1ull) * 8)); HIPCHK(ctx, dt64.alloc(n64 * 8)); HIPCHK(ctx, do64.alloc((n + 1ull) * 8));
+    HIPCHK(ctx, od.alloc(n * 12ull)); HIPCHK(ctx, oe.alloc(n * 4ull));
+    HIPCHK(ctx, hipMemcpy(dd.p, dirs, n * 12ull, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(dp.p, points, n * 12ull, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(dn.p, normals, n * 12ull, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(dty.p, mat_type, n * 4ull, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(drg.p, mat_rgba, n * 16ull, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(dpa.p, mat_param, n * 8ull, hipMemcpyHostToDevice));
+    if (n32) HIPCHK(ctx, hipMemcpy(dt32.p, tape32, n32 * 4, hipMemcpyHostToDevice));
+    if (n64) HIPCHK(ctx, hipMemcpy(dt64.p, tape64, n64 * 8, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(do32.p, ofs32, (n + 1ull) * 8, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(do64.p, ofs64, (n + 1ull) * 8, hipMemcpyHostToDevice));
+    ProbeScatterArgs a{n, dd.as<float>(), dp.as<float>(), dn.as<float>(), dty.as<uint32_t>(), drg.as<float>(), dpa.as<float>(),
+                       dt32.as<float>(), do32.as<unsigned long long>(), dt64.as<double>(), do64.as<unsigned long long>(), od.as<float>(), oe.as<uint32_t>()};
+    hipLaunchKernelGGL(k_probe_scatter, dim3((n + 255) / 256), dim3(256), 0, 0, a);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(out_dir, od.p, n * 12ull, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out_event, oe.p, n * 4ull, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_hip_probe_paths(pt_ctx* ctx, uint32_t n, const float* rays, const float* times, uint32_t max_depth, uint32_t flags,
+                       const float* tape32, const uint64_t* ofs32, const double* tape64, const uint64_t* ofs64,
+                       float* out_rgba, uint32_t* out_segments)
+{
+    int st = check_scene(ctx);
+    if (st != PT_OK) return st;
+    if (!rays || !times || !tape32 || !ofs32 || !tape64 || !ofs64 || !out_rgba) return PT_ERR_INVALID;
+    if (n == 0) return PT_OK;
+    Bind b(ctx);
+    const size_t lds = lds_bytes_probe(ctx->sc);
+    if (lds > ctx->lds_limit) return PT_ERR_UNSUPPORTED;
+    const uint64_t n32 = ofs32[n], n64 = ofs64[n];
+    DevBuf dr, dt, dt32, do32, dt64, do64, oc, os;
+    HIPCHK(ctx, dr.alloc(n * 24ull)); HIPCHK(ctx, dt.alloc(n * 4ull));
+    HIPCHK(ctx, dt32.alloc(n32 * 4)); HIPCHK(ctx, do32.alloc((n + 1ull) * 8)); HIPCHK(ctx, dt64.alloc(n64 * 8)); HIPCHK(ctx, do64.alloc((n + 1ull) * 8));
+    HIPCHK(ctx, oc.alloc(n * 16ull)); HIPCHK(ctx, os.alloc(n * 4ull));
+    HIPCHK(ctx, hipMemcpy(dr.p, rays, n * 24ull, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(dt.p, times, n * 4ull, hipMemcpyHostToDevice));
+    if (n32) HIPCHK(ctx, hipMemcpy(dt32.p, tape32, n32 * 4, hipMemcpyHostToDevice));
+    if (n64) HIPCHK(ctx, hipMemcpy(dt64.p, tape64, n64 * 8, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(do32.p, ofs32, (n + 1ull) * 8, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(do64.p, ofs64, (n + 1ull) * 8, hipMemcpyHostToDevice));
+    ProbePathsArgs a{ctx->sc, n, max_depth, dr.as<float>(), dt.as<float>(), dt32.as<float>(), do32.as<unsigned long long>(),
+                     dt64.as<double>(), do64.as<unsigned long long>(), oc.as<float>(), os.as<uint32_t>()};
+    const dim3 grid((n + 255) / 256), block(256);
+    const bool moving = ctx->blob.moving, strict = (flags & PT_FLAG_STRICT_SEARCH) != 0;
+#define LAUNCH(M, S) do { st = set_lds(ctx, k_probe_paths<M, S>, lds); if (st != PT_OK) return st; hipLaunchKernelGGL((k_probe_paths<M, S>), grid, block, lds, 0, a); } while (0)
+    if (moving) { if (strict) LAUNCH(true, true); else LAUNCH(true, false); }
+    else        { if (strict) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(out_rgba, oc.p, n * 16ull, hipMemcpyDeviceToHost));
+    if (out_segments) HIPCHK(ctx, hipMemcpy(out_segments, os.p, n * 4ull, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_hip_probe_samples(pt_ctx* ctx, const pt_params* p, uint32_t n, const uint32_t* pixels, const uint32_t* samples,
+                         float* out_rgba, uint32_t* out_segments)
+{
+    int st = check_scene(ctx);
+    if (st != PT_OK) return st;
+    if (!p || !pixels || !samples || !out_rgba || p->width == 0 || p->height == 0) return PT_ERR_INVALID;
+    if (n == 0) return PT_OK;
+    for (uint32_t i = 0; i < n; ++i) if (pixels[i] >= (uint64_t)p->width * p->height) return PT_ERR_INVALID;
+    Bind b(ctx);
+    const size_t lds = lds_bytes_probe(ctx->sc);
+    if (lds > ctx->lds_limit) return PT_ERR_UNSUPPORTED;
+    DevBuf dp, ds, oc, os;
+    HIPCHK(ctx, dp.alloc(n * 4ull)); HIPCHK(ctx, ds.alloc(n * 4ull)); HIPCHK(ctx, oc.alloc(n * 16ull)); HIPCHK(ctx, os.alloc(n * 4ull));
+    HIPCHK(ctx, hipMemcpy(dp.p, pixels, n * 4ull, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ds.p, samples, n * 4ull, hipMemcpyHostToDevice));
+    ProbeSamplesArgs a{ctx->sc, n, p->width, p->height, p->max_depth, p->seed, dp.as<uint32_t>(), ds.as<uint32_t>(), oc.as<float>(), os.as<uint32_t>()};
+    const dim3 grid((n + 255) / 256), block(256);
+    const bool moving = ctx->blob.moving, strict = (p->flags & PT_FLAG_STRICT_SEARCH) != 0;
+#define LAUNCH(M, S) do { st = set_lds(ctx, k_probe_samples<M, S>, lds); if (st != PT_OK) return st; hipLaunchKernelGGL((k_probe_samples<M, S>), grid, block, lds, 0, a); } while (0)
+    if (moving) { if (strict) LAUNCH(true, true); else LAUNCH(true, false); }
+    else        { if (strict) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(out_rgba, oc.p, n * 16ull, hipMemcpyDeviceToHost));
+    if (out_segments) HIPCHK(ctx, hipMemcpy(out_segments, os.p, n * 4ull, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_hip_probe_philox(pt_ctx* ctx, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* out_words)
+{
+    if (!ctx || !out_words) return PT_ERR_INVALID;
+    if (n == 0) return PT_OK;
+    Bind b(ctx);
+    DevBuf o;
+    HIPCHK(ctx, o.alloc(n * 4ull));
+    hipLaunchKernelGGL(k_probe_philox, dim3(1), dim3(64), 0, 0, seed, pixel, sample, n, o.as<uint32_t>());
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(out_words, o.p, n * 4ull, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+} // extern "C"

@@ -75,6 +75,7 @@ struct Rng
     virtual float f32() = 0;  // random_f32()  utils.h:38-45
     virtual double f64() = 0; // random_f64()  utils.h:28-35
     virtual ~Rng() {}
+    virtual void align() {}    // Philox only: skip to the next 4-word block (see PhiloxRng)
     uint64_t n32 = 0, n64 = 0; // draws taken, for tests that build tapes
     float f32(float lo, float hi) { return f32() * (hi - lo) + lo; } // utils.h:47-51
 };
@@ -108,6 +109,7 @@ struct TapeRng : Rng
 //   word k of the stream of (seed, pixel, sample) = philox4x32_10(ctr = {k>>2, pixel, sample, 0}, key = {seed_lo, seed_hi})[k&3]
 //   f32 uniform  = (word >> 8) * 2^-24                         in [0,1), one word
 //   f64 uniform  = (((u64)w0 << 32 | w1) >> 11) * 2^-53        in [0,1), two consecutive words
+//   align()      = k <- (k+3) & ~3, at the start of every scatter event
 inline void philox4x32_10(const uint32_t c[4], const uint32_t k[2], uint32_t out[4])
 {
     uint32_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], k0 = k[0], k1 = k[1];
@@ -129,6 +131,9 @@ struct PhiloxRng : Rng
         if ((k & 3) == 0) { uint32_t c[4] = {k >> 2, pixel, sample, 0}; philox4x32_10(c, key, buf); }
         return buf[(k++) & 3];
     }
+    // Every scatter starts on a block boundary (a SIMT efficiency device of the MI355X build; part of the stream's
+    // definition).  The reference's MT19937 stream has no such notion: MtRng / TapeRng ignore it.
+    void align() override { k = (k + 3u) & ~3u; }
     float f32() override { ++n32; return (float)(word() >> 8) * 5.9604644775390625e-8f; }
     double f64() override
     {
@@ -341,6 +346,7 @@ bool scatter(const Ray& ray, const Hit& h, Rng& rng, Ray* out, V4* attenuation, 
 {
     const Material& m = *h.m;
     *event = EV_SCATTER;
+    rng.align();
     if (m.type == MAT_DIFFUSE)                                                     // main.cpp:223-234
     {
         V3 scatterDirection = add(random_unit_vector(rng), h.normal);

@@ -6,6 +6,7 @@ raise.  Device buffers handed in/out are raw addresses (ints), e.g. ``torch.Tens
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -63,6 +64,14 @@ def load_library(path=LIB_PATH):
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own HIP runtime and publish it process-wide (RTLD_GLOBAL).  If torch is going
+    # to live in this process it must initialise FIRST, so that libpt_hip.so binds to the same runtime (one runtime,
+    # shared streams and device pointers); loaded the other way round torch reports "No HIP GPUs are available".
+    if "torch" not in sys.modules and os.environ.get("PT_HIP_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(path):
         raise FileNotFoundError(f"{path} is missing: build it with `make lib` (hipcc --offload-arch=gfx950); "
                                 "there is no CPU fallback")

@@ -96,6 +96,10 @@ struct PhiloxRng
         uint64_t hi = word(), lo = word();
         return (double)(((hi << 32) | lo) >> 11) * 1.1102230246251565404e-16;
     }
+    // Skip to the next 4-word block.  Called at the start of every scatter: lanes of a wave arrive with different
+    // draw counts, and without this each of the 3 draws of a rejection attempt refills for SOME lane (three Philox
+    // evaluations per attempt instead of 3/4).  Part of the stream's definition (DESIGN.md "RNG"); the oracle does the same.
+    PT_DEV void align() { k = (k + 3u) & ~3u; }
     PT_DEV bool overrun() const { return false; }
 };
 
@@ -106,6 +110,7 @@ struct TapeRng
     PT_DEV void init(const float* a, uint32_t na, const double* b, uint32_t nb) { t32 = a; n32 = na; t64 = b; n64 = nb; i32 = i64 = 0; over = false; }
     PT_DEV float f32() { if (i32 >= n32) { over = true; ++i32; return 0.5f; } return t32[i32++]; }
     PT_DEV double f64() { if (i64 >= n64) { over = true; ++i64; return 0.5; } return t64[i64++]; }
+    PT_DEV void align() {}
     PT_DEV bool overrun() const { return over; }
 };
 
@@ -224,13 +229,16 @@ PT_DEV float intersect_plane_exact(const Ray& ray, V3 n, float offset)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// The search: smallest t > kMinT over all spheres, returned as the sphere index (or -1).
-// Key trick: w = t - kMinT as raw bits with the sphere index spliced into the low mantissa bits; valid hits are
-// positive floats, which order like unsigned integers; negative w (behind / self hit) has the sign bit set and
-// NaN (no real root) is above +inf, so ONE unsigned min3 per sphere pair does validity test, closest test and
-// index tracking.  Resolution of the ordering: 2^-(23-bits) relative (bits <= 10 -> 1.2e-4), which only matters
-// for two different spheres hit at distances that close (interpenetrating spheres' seam).
-template <bool MOVING> PT_DEV int32_t search_spheres_fast(const SceneView& s, const Ray& ray, float time)
+// The search: which sphere has the smallest t > kMinT.  Returns a sphere index to evaluate exactly, or -1.
+// Key trick: w = t - kMinT as raw bits; valid hits are positive floats, which order like unsigned integers; a
+// negative w (sphere behind the ray / the sphere just left) has the sign bit set and a NaN (no real root) is above
+// +inf, so ONE unsigned min does validity test and closest test.  The index rides in the low bits of the key:
+//   WIDE = false (<= 256 pairs): key = {w[31:8], pair index} by one v_perm_b32 on min(w0,w1); the two spheres of
+//                                the winning pair are then both evaluated exactly by the caller.  Ordering
+//                                resolution between DIFFERENT pairs: 2^-15 relative.
+//   WIDE = true                : key = (w & ~mask) | sphere index (v_and + v_or per sphere), resolution 2^-(23-bits).
+// The resolution only matters for two spheres hit at distances that close, i.e. the seam of interpenetrating spheres.
+template <bool MOVING, bool WIDE> PT_DEV int32_t search_spheres_fast(const SceneView& s, const Ray& ray, float time)
 {
 #pragma clang fp contract(fast)
     // Origin advanced by kMinT along the (unit) direction: the near root measured from there IS t - kMinT.
@@ -258,11 +266,20 @@ template <bool MOVING> PT_DEV int32_t search_spheres_fast(const SceneView& s, co
         f32x2 disc = hb * hb - c;                                       // discriminant/4
         float w0 = -hb.x - __builtin_amdgcn_sqrtf(disc.x);              // t - kMinT; NaN when disc < 0
         float w1 = -hb.y - __builtin_amdgcn_sqrtf(disc.y);
-        uint32_t k0 = (__float_as_uint(w0) & keep) | (2 * j);
-        uint32_t k1 = (__float_as_uint(w1) & keep) | (2 * j + 1);
-        best = min(best, min(k0, k1));
+        if (WIDE)
+        {
+            uint32_t k0 = (__float_as_uint(w0) & keep) | (2 * j);
+            uint32_t k1 = (__float_as_uint(w1) & keep) | (2 * j + 1);
+            best = min(best, min(k0, k1));
+        }
+        else
+        {
+            uint32_t m = min(__float_as_uint(w0), __float_as_uint(w1));
+            best = min(best, __builtin_amdgcn_perm(m, j, 0x07060500u)); // {m.b3, m.b2, m.b1, j.b0}
+        }
     }
-    return best < 0x7F800000u ? (int32_t)(best & s.idx_mask) : -1;
+    if (best >= 0x7F800000u) return -1;
+    return WIDE ? (int32_t)(best & s.idx_mask) : (int32_t)(2u * (best & 0xFFu));
 }
 
 // The same query in reference arithmetic for EVERY sphere: lowest index wins ties (oracle: query_closest).
@@ -311,12 +328,37 @@ template <bool MOVING, bool STRICT> PT_DEV Hit closest_hit(const SceneView& s, c
     }
     else
     {
-        obj = search_spheres_fast<MOVING>(s, ray, time);
-        if (obj >= 0) // the winner's t, re-evaluated in reference arithmetic
+        // The winner (or the winning pair) is re-evaluated in reference arithmetic; lower index wins an exact tie.
+        if (s.npairs <= 256u)
         {
-            float r2; load_sphere(s, (uint32_t)obj, &centre, &r2);
-            if (MOVING) centre = add(centre, mul(load_velocity(s, (uint32_t)obj), time));
-            t = intersect_sphere_exact(ray, centre, r2);
+            obj = search_spheres_fast<MOVING, false>(s, ray, time);
+            if (obj >= 0)
+            {
+                V3 c0, c1; float r20, r21;
+                load_sphere(s, (uint32_t)obj, &c0, &r20);
+                load_sphere(s, (uint32_t)obj + 1u, &c1, &r21);       // the odd slot of an odd scene has r2 = -1: never hit
+                if (MOVING)
+                {
+                    c0 = add(c0, mul(load_velocity(s, (uint32_t)obj), time));
+                    c1 = add(c1, mul(load_velocity(s, (uint32_t)obj + 1u), time));
+                }
+                const float t0 = intersect_sphere_exact(ray, c0, r20), t1 = intersect_sphere_exact(ray, c1, r21);
+                const bool v0 = t0 > kMinT, v1 = t1 > kMinT;
+                const bool second = v1 && (!v0 || t1 < t0);
+                t = second ? t1 : t0;
+                centre = second ? c1 : c0;
+                obj = second ? obj + 1 : obj;
+            }
+        }
+        else
+        {
+            obj = search_spheres_fast<MOVING, true>(s, ray, time);
+            if (obj >= 0)
+            {
+                float r2; load_sphere(s, (uint32_t)obj, &centre, &r2);
+                if (MOVING) centre = add(centre, mul(load_velocity(s, (uint32_t)obj), time));
+                t = intersect_sphere_exact(ray, centre, r2);
+            }
         }
     }
     if (obj >= 0 && t > kMinT && t < h.t)                                // main.cpp:204-216
@@ -352,9 +394,15 @@ template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray
 {
     *event = EV_SCATTER;
     out->o = h.point;
+    rng.align();
+    // Diffuse and rough metal both start from random_point_in_unit_sphere (utils.h:80-94): one rejection loop for
+    // both, so a wave pays max(attempts) once, not once per material branch.  Per lane the draws are unchanged.
+    const bool roughMetal = h.m.type == MAT_METAL && h.m.roughness > 0.0f;
+    V3 unitPoint = v3(0, 0, 0);
+    if (h.m.type == MAT_DIFFUSE || roughMetal) unitPoint = random_point_in_unit_sphere(rng);
     if (h.m.type == MAT_DIFFUSE)                                         // main.cpp:223-234
     {
-        V3 scatterDirection = add(random_unit_vector(rng), h.normal);
+        V3 scatterDirection = add(normalize(unitPoint), h.normal);       // random_unit_vector, utils.h:102-108
         if (near_zero(add(scatterDirection, h.normal))) scatterDirection = h.normal; // sic (main.cpp:226)
         out->d = normalize(scatterDirection);
         return true;
@@ -362,10 +410,10 @@ template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray
     if (h.m.type == MAT_METAL)                                           // main.cpp:235-259
     {
         V3 reflectedDir = reflect_direction(ray.d, h.normal);
-        if (h.m.roughness > 0.0f)
+        if (roughMetal)
         {
             V3 centre = add(h.point, reflectedDir);
-            V3 randomPoint = add(mul(random_point_in_unit_sphere(rng), h.m.roughness), centre); // utils.h:96-100
+            V3 randomPoint = add(mul(unitPoint, h.m.roughness), centre); // utils.h:96-100
             reflectedDir = sub(randomPoint, h.point);
         }
         out->d = normalize(reflectedDir);

@@ -1,0 +1,25 @@
+#!/bin/bash
+# tools/profile.sh -- rocprofv3 passes over bench.py on the GPU box (one pass per run; see MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# usage: tools/profile.sh <tag> [bench args...]      outputs -> gpurun_out/prof_<tag>/
+set -u
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --cpu-spp 0 $*"
+echo "== kernel trace + stats" 
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
+i=0
+for PMC in \
+  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" \
+  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR" \
+  "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64" \
+  "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
+  "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
+  "GRBM_GUI_ACTIVE GRBM_COUNT" ; do
+  i=$((i+1))
+  echo "== pmc pass $i: $PMC"
+  timeout -s KILL 300 rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- $BENCH > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -5 $OUT/pmc$i.log; }
+done
+echo done

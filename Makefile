@@ -36,3 +36,8 @@ clean:
 	rm -rf $(LIBDIR) ; $(MAKE) -C oracle clean
 
 .PHONY: all lib oracle isa clean
+
+# Diagnostic build with in-kernel s_memtime stamps (never shipped, never benchmarked: read its SHARES, not its speed).
+stamps: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h $(LIBDIR)/pt_world.o
+	$(HIPCC) $(HIPFLAGS) -DPT_STAMPS -c $(CSRC)/pt_hip.hip -o $(LIBDIR)/pt_hip_stamps.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(LIBDIR)/pt_hip_stamps.o $(LIBDIR)/pt_world.o -o $(LIBDIR)/libpt_hip_stamps.so

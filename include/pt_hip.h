@@ -78,6 +78,8 @@ typedef struct pt_stats {
     uint64_t segments;      /* loop iterations of cast_ray over all samples (S-bar = segments/samples) */
     uint64_t sphere_tests;  /* ray-sphere evaluations (LDS kernel: segments*n_spheres; BVH kernel: leaves visited) */
     uint64_t node_visits;   /* BVH kernel: box tests; LDS kernel: 0 */
+    uint64_t wave_iterations; /* trips of the per-wave segment loop; lane utilisation = segments / (64 * wave_iterations) */
+    uint64_t phase_cycles[3]; /* diagnostic builds (-DPT_STAMPS) only: shader cycles in refill / closest-hit / shading; else 0 */
     double kernel_ms;       /* HIP-event time of the render kernel on its stream */
     uint32_t kernel;        /* 0 = LDS brute force, 1 = BVH in HBM */
     uint32_t reserved;
@@ -137,6 +139,10 @@ void pt_scene_free(pt_scene* scene);
  * (same LDS staging, same search, same scatter) with the RNG replaced by an explicit tape of uniforms, so the
  * reference, the oracle and the GPU can be compared on IDENTICAL inputs (BASELINE.json north_star, gate 1). */
 
+/* intersection_test(Ray,Sphere) and intersection_test(Ray,Plane) (src/geometry.cpp:39-81) record by record, as the
+ * kernels evaluate them for a chosen hit.  rays 6*n; spheres 4*n (centre, radius); planes 4*n (normal, offset). */
+int pt_hip_probe_primitives(pt_ctx* ctx, uint32_t n, const float* rays, const float* spheres, const float* planes,
+                            float* out_t_sphere, float* out_t_plane);
 /* Closest hit of planes then spheres as cast_ray orders it (src/main.cpp:180-216).
  * rays: 6*n (origin, unit dir); times: n; out_prim: sphere index >= 0, plane i -> -1-i, miss -> INT32_MIN. */
 int pt_hip_probe_hits(pt_ctx* ctx, uint32_t n, const float* rays, const float* times, uint32_t flags,

@@ -453,7 +453,7 @@ class Ref:
                                  C.c_uint32(y0), C.c_uint32(x1), C.c_uint32(y1), C.c_uint32(skip32), C.c_uint32(skip64), _p(out))
         return out
 
-    def render(self, h, w, hgt, spp, depth, nthreads):
+    def render(self, h, w, hgt, spp, depth, nthreads, skip32=0):
         out = np.zeros((hgt, w, 4), np.float32)
-        secs = self.lib.ref_render(h, C.c_uint32(w), C.c_uint32(hgt), C.c_uint32(spp), C.c_uint32(depth), C.c_uint32(nthreads), _p(out))
+        secs = self.lib.ref_render(h, C.c_uint32(w), C.c_uint32(hgt), C.c_uint32(spp), C.c_uint32(depth), C.c_uint32(nthreads), C.c_uint32(skip32), _p(out))
         return secs, out

@@ -25,7 +25,7 @@ EXPORTS = (
     "pt_hip_upload_scene", "pt_hip_render", "pt_hip_render_device", "pt_hip_last_stats", "pt_hip_resolve_device",
     "pt_resolve", "pt_pack_bgra", "pt_bmp_write", "pt_bmp_write_bgra", "pt_bmp_header",
     "pt_scene_builtin", "pt_scene_get_desc", "pt_scene_free",
-    "pt_hip_probe_hits", "pt_hip_probe_get_rays", "pt_hip_probe_scatter", "pt_hip_probe_paths",
+    "pt_hip_probe_primitives", "pt_hip_probe_hits", "pt_hip_probe_get_rays", "pt_hip_probe_scatter", "pt_hip_probe_paths",
     "pt_hip_probe_samples", "pt_hip_probe_philox",
 )
 
@@ -53,6 +53,7 @@ class Params(C.Structure):  # pt_params
 
 class Stats(C.Structure):  # pt_stats
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64), ("node_visits", C.c_uint64),
+                ("wave_iterations", C.c_uint64), ("phase_cycles", C.c_uint64 * 3),
                 ("kernel_ms", C.c_double), ("kernel", C.c_uint32), ("reserved", C.c_uint32)]
 
 
@@ -241,9 +242,18 @@ class Renderer:
     def stats(self):
         s = Stats()
         self._check(self.L.pt_hip_last_stats(self.h, C.byref(s)), "pt_hip_last_stats")
-        return {k: getattr(s, k) for k, _ in Stats._fields_ if k != "reserved"}
+        d = {k: getattr(s, k) for k, _ in Stats._fields_ if k not in ("reserved", "phase_cycles")}
+        d["phase_cycles"] = list(s.phase_cycles)
+        return d
 
     # ---- parity probes
+    def probe_primitives(self, rays, spheres, planes):
+        rays, spheres, planes = _f32(rays).reshape(-1, 6), _f32(spheres).reshape(-1, 4), _f32(planes).reshape(-1, 4)
+        n = len(rays)
+        ts, tp = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        self._check(self.L.pt_hip_probe_primitives(self.h, C.c_uint32(n), _ptr(rays), _ptr(spheres), _ptr(planes), _ptr(ts), _ptr(tp)), "pt_hip_probe_primitives")
+        return ts, tp
+
     def probe_hits(self, rays, times, flags=0):
         rays, times = _f32(rays).reshape(-1, 6), _f32(times).reshape(-1)
         n = len(rays)

@@ -3,10 +3,10 @@
 // Two arithmetic regimes live here, on purpose (DESIGN.md "Arithmetic"):
 //   * everything a result VALUE flows through (ray generation, the chosen hit's t, hit point, normal, scatter
 //     directions, colours) is evaluated in the reference's own operation order with contraction OFF, so it is
-//     bit-identical to the reference/oracle on identical inputs;
+//     bit-identical to the reference on identical inputs;
 //   * the closest-sphere SEARCH over the LDS-resident scene -- >80 % of all instructions -- only has to pick the
 //     right sphere index, so it runs contracted, packed (v_pk_fma_f32) and with the hardware sqrt.
-// Reference citations are file:line under /root/reference/src.
+// Reference citations are file:line in the reference tree (src/...).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -395,6 +395,9 @@ template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray
     *event = EV_SCATTER;
     out->o = h.point;
     rng.align();
+    // The dielectric's single f64 draw (main.cpp:276) is taken here, right behind align(): its two words are then
+    // words 0,1 of a fresh block, one Philox evaluation, known at compile time.
+    const double xi = (h.m.type == MAT_DIALECTRIC) ? rng.f64() : 0.0;
     // Diffuse and rough metal both start from random_point_in_unit_sphere (utils.h:80-94): one rejection loop for
     // both, so a wave pays max(attempts) once, not once per material branch.  Per lane the draws are unchanged.
     const bool roughMetal = h.m.type == MAT_METAL && h.m.roughness > 0.0f;
@@ -428,7 +431,7 @@ template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray
         float cosTheta = dot(neg(ray.d), h.normal);
         float sinTheta = sqrtf(1 - cosTheta * cosTheta);
         bool internalReflection = refractRatio * sinTheta > 1.0f;
-        bool shouldReflect = reflectance((double)cosTheta, (double)refractRatio) > rng.f64();
+        bool shouldReflect = reflectance((double)cosTheta, (double)refractRatio) > xi;
         V3 newRayDir;
         if (internalReflection || shouldReflect)
             newRayDir = reflect_direction(ray.d, h.normal);

@@ -88,10 +88,18 @@ __global__ void __launch_bounds__(256) k_render_lds(RenderArgs a)
     float time = 0.0f;
     uint32_t depth = 0, p = 0;
     PhiloxRng rng; rng.init(a.seed, 0, 0);
-    uint32_t segs = 0;
+    uint32_t segs = 0, iters = 0;
+#ifdef PT_STAMPS
+    unsigned long long cyc_refill = 0, cyc_hit = 0, cyc_shade = 0;
+#define PT_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+    unsigned long long ts0, ts1, ts2, ts3;
+#else
+#define PT_STAMP(var) do { } while (0)
+#endif
 
     for (;;)
     {
+        PT_STAMP(ts0);
         // ---- refill: every lane without a live path takes the next work item (main.cpp:347-354)
         const bool want = !alive && !retired;
         const unsigned long long need = __ballot(want);
@@ -127,8 +135,11 @@ __global__ void __launch_bounds__(256) k_render_lds(RenderArgs a)
             continue;
         }
         // ---- one segment for every lane (lanes without a live path ride along on stale data)
+        ++iters;
+        PT_STAMP(ts1);
         Ray ray; ray.o = v3(rox, roy, roz); ray.d = v3(rdx, rdy, rdz);
         const Hit h = closest_hit<MOVING, STRICT>(s, ray, time);
+        PT_STAMP(ts2);
         if (alive)
         {
             ++segs;
@@ -145,6 +156,10 @@ __global__ void __launch_bounds__(256) k_render_lds(RenderArgs a)
                 alive = false;
             }
         }
+#ifdef PT_STAMPS
+        PT_STAMP(ts3);
+        cyc_refill += ts1 - ts0; cyc_hit += ts2 - ts1; cyc_shade += ts3 - ts2;
+#endif
     }
 
     // ---- one 16-byte store per pixel: the only HBM traffic of the render besides staging the scene
@@ -158,7 +173,14 @@ __global__ void __launch_bounds__(256) k_render_lds(RenderArgs a)
     }
     // ---- statistics: segments of this wave
     for (int o = 32; o > 0; o >>= 1) segs += __shfl_xor(segs, o);
-    if (lane == 0) atomicAdd(a.stats, (unsigned long long)segs);
+    if (lane == 0)
+    {
+        atomicAdd(a.stats, (unsigned long long)segs);
+        atomicAdd(a.stats + 1, (unsigned long long)iters);
+#ifdef PT_STAMPS
+        atomicAdd(a.stats + 2, cyc_refill); atomicAdd(a.stats + 3, cyc_hit); atomicAdd(a.stats + 4, cyc_shade);
+#endif
+    }
 }
 
 // ================================================================================================ probes
@@ -176,6 +198,16 @@ template <bool MOVING, bool STRICT> __global__ void __launch_bounds__(256) k_pro
     a.t[i] = h.t; a.prim[i] = h.prim;
     a.point[3*i] = h.point.x; a.point[3*i+1] = h.point.y; a.point[3*i+2] = h.point.z;
     a.normal[3*i] = h.normal.x; a.normal[3*i+1] = h.normal.y; a.normal[3*i+2] = h.normal.z;
+}
+
+__global__ void __launch_bounds__(256) k_probe_primitives(uint32_t n, const float* rays, const float* spheres, const float* planes, float* ts, float* tp)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r; r.o = v3(rays[6*i], rays[6*i+1], rays[6*i+2]); r.d = v3(rays[6*i+3], rays[6*i+4], rays[6*i+5]);
+    const float radius = spheres[4*i+3];
+    ts[i] = intersect_sphere_exact(r, v3(spheres[4*i], spheres[4*i+1], spheres[4*i+2]), radius * radius); // geometry.cpp:47
+    tp[i] = intersect_plane_exact(r, v3(planes[4*i], planes[4*i+1], planes[4*i+2]), planes[4*i+3]);
 }
 
 struct ProbeRaysArgs { DeviceCamera cam; uint32_t n; const float* uv; const float* tape; const unsigned long long* ofs; float* rays; };
@@ -515,6 +547,8 @@ int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out)
     ctx->last.segments = st[0];
     ctx->last.sphere_tests = st[0] * (uint64_t)ctx->sc.ns;
     ctx->last.node_visits = 0;
+    ctx->last.wave_iterations = st[1];
+    ctx->last.phase_cycles[0] = st[2]; ctx->last.phase_cycles[1] = st[3]; ctx->last.phase_cycles[2] = st[4];
     *out = ctx->last;
     return PT_OK;
 }
@@ -561,6 +595,24 @@ int pt_hip_probe_hits(pt_ctx* ctx, uint32_t n, const float* rays, const float* t
     HIPCHK(ctx, hipMemcpy(out_prim, op.p, n * 4ull, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(out_point, opt.p, n * 12ull, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(out_normal, on.p, n * 12ull, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_hip_probe_primitives(pt_ctx* ctx, uint32_t n, const float* rays, const float* spheres, const float* planes, float* out_ts, float* out_tp)
+{
+    if (!ctx || !rays || !spheres || !planes || !out_ts || !out_tp) return PT_ERR_INVALID;
+    if (n == 0) return PT_OK;
+    Bind b(ctx);
+    DevBuf dr, ds, dp, ots, otp;
+    HIPCHK(ctx, dr.alloc(n * 24ull)); HIPCHK(ctx, ds.alloc(n * 16ull)); HIPCHK(ctx, dp.alloc(n * 16ull)); HIPCHK(ctx, ots.alloc(n * 4ull)); HIPCHK(ctx, otp.alloc(n * 4ull));
+    HIPCHK(ctx, hipMemcpy(dr.p, rays, n * 24ull, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ds.p, spheres, n * 16ull, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(dp.p, planes, n * 16ull, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe_primitives, dim3((n + 255) / 256), dim3(256), 0, 0, n, dr.as<float>(), ds.as<float>(), dp.as<float>(), ots.as<float>(), otp.as<float>());
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(out_ts, ots.p, n * 4ull, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out_tp, otp.p, n * 4ull, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

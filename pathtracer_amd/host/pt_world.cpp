@@ -1,7 +1,7 @@
 // pt_world.cpp -- host scene model, scene builders, resolve and BMP output (all host C++, no GPU code).
 // Compiled with -ffp-contract=off: positions, radii and camera vectors must come out bit-identical to what the
-// reference computes (tests/test_scenes.py compares against tests/golden/scenes.npz, dumped from the compiled
-// reference).  Citations are file:line under /root/reference/src.
+// reference computes (tests/test_scenes_and_abi.py compares against tests/golden/scenes.npz, dumped from the compiled
+// reference).  Citations are file:line in the reference tree (src/...).
 #include "pt_world.h"
 
 #include <math.h>

@@ -190,8 +190,12 @@ def test_converged_image_vs_reference_renderer(renderer, golden_dir):
         renderer.upload(pt.Scene.builtin(sid, w / h))
         img = pt.resolve(renderer.render(w, h, 0, spp, depth, seed=123), spp).reshape(h, w, 4)
         p, m = psnr(img[..., :3], ref[..., :3]), mean_rel_error(img, ref)
-        # The GPU image is an independent Monte Carlo estimate: it can be no closer to the reference image than a second
-        # reference run is (the noise floor).  Gate: within 1 dB / 10 % of that floor, and the absolute bars of BASELINE.md.
-        assert p >= floor_psnr - 1.0, (key, p, floor_psnr)
-        assert m <= floor_mre * 1.10 + 1e-4, (key, m, floor_mre)
-        assert p >= 35.0 and m <= 0.02, (key, p, m)
+        # The GPU image is an independent Monte Carlo estimate, so it can be no closer to the reference image than a
+        # second reference run is (the noise floor stored with the fixture: ~50.7 dB / 0.31 % for scene 1 at 4096 spp).
+        # On top of the noise sits decision D1 (true closest hit instead of the reference BVH's pairwise-combine quirk):
+        # tools/d1_check.py shows the oracle reaches the floor (50.6 dB) with the quirk and 44.0 dB without it, and the
+        # GPU lands on that same 44.0 dB.  Stated thresholds: PSNR >= 40 dB and mean relative error <= 1.5 x floor
+        # (both far inside BASELINE.md's proposed bars of 35 dB / 2 %).
+        print(f"{key}: PSNR {p:.2f} dB (floor {floor_psnr:.2f}), mean rel err {m:.5f} (floor {floor_mre:.5f})")
+        assert p >= 40.0, (key, p, floor_psnr)
+        assert m <= floor_mre * 1.5, (key, m, floor_mre)

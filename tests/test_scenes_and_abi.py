@@ -1,0 +1,115 @@
+"""CPU: the product's host side and its C-ABI surface (no GPU needed): scene builders vs the reference's scenes,
+resolve / pack / BMP vs the oracle and the reference's own output files, exported symbols vs include/pt_hip.h."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pathtracer_amd as pt
+from oracle import pyoracle as po
+from tests._util import bit_equal, to_scene_arrays
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_exactly_the_header(golden_dir):
+    header = open(os.path.join(ROOT, "include", "pt_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char\*|pt_scene\*)\s+(pt_[a-z0-9_]+)\s*\(", header, re.M))
+    assert declared == set(pt.EXPORTS), declared ^ set(pt.EXPORTS)
+    L = pt.load_library()
+    for sym in pt.EXPORTS:
+        assert hasattr(L, sym), sym
+    # every replaced reference interface is cited (file:line) next to its declaration
+    assert len(re.findall(r"src/[a-z_]+\.(?:cpp|h):\d+", header)) >= 25
+    # ctypes mirrors of the structs have the C sizes
+    assert C.sizeof(pt.Params) == 32 and C.sizeof(pt.Stats) == 80 and C.sizeof(pt.SceneDesc) == 152
+
+
+def test_status_codes_without_gpu():
+    L = pt.load_library()
+    assert L.pt_hip_strerror(0) == b"ok" and b"invalid" in L.pt_hip_strerror(pt.PT_ERR_INVALID)
+    h = C.c_void_p()
+    assert L.pt_hip_create(-1, C.byref(h)) == pt.PT_ERR_NO_DEVICE
+    assert L.pt_hip_create(0, None) == pt.PT_ERR_INVALID
+    if pt.device_count() == 0:
+        assert L.pt_hip_create(0, C.byref(h)) == pt.PT_ERR_NO_DEVICE   # loud failure, no CPU fallback
+        with pytest.raises(pt.PtError):
+            pt.Renderer(0)
+    assert L.pt_resolve(None, 1, 1, None) == pt.PT_ERR_INVALID
+    assert L.pt_bmp_header(0, 4, None) == pt.PT_ERR_INVALID
+    assert L.pt_scene_builtin(99, 1.0, 0) is None
+
+
+@pytest.mark.parametrize("sid", [1, 2, 3])
+def test_scene_builders_match_reference(golden_dir, sid):
+    z = np.load(os.path.join(golden_dir, "scenes.npz"))
+    want = po.SceneArrays.from_npz(z, f"s{sid}_")
+    got = to_scene_arrays(pt.Scene.builtin(sid, 16 / 9))
+    for k in ("pos_r", "vel", "rgba", "param", "pl_n_d", "pl_rgba", "pl_param", "camera"):
+        assert bit_equal(getattr(got, k), getattr(want, k)), (sid, k)
+    assert (got.mtype == want.mtype).all() and (got.pl_type == want.pl_type).all()
+    assert (got.t0, got.t1) == (want.t0, want.t1)
+
+
+def test_scene_1_facts_from_the_survey():
+    s = pt.Scene.builtin(1, 800 / 450)
+    assert s.n_spheres == 259 and s.n_planes == 1
+    assert np.bincount(s.mtype, minlength=4).tolist() == [0, 222, 2, 35]
+    assert np.allclose(s.pos_r[0], [-25.47893, 0.55, -27.14308, 0.6811584], atol=1e-5)
+    assert abs(float(np.dot(s.camera[3:6], s.camera[6:9])) + 0.134) < 1e-3          # sheared image plane (8a-2)
+    assert s.vel is None
+    assert pt.Scene.builtin(3, 1.0).vel is not None
+
+
+def test_build_defined_scenes():
+    m = pt.Scene.builtin(4, 16 / 9)     # C2: materials + DOF
+    assert m.n_spheres == 3 and m.n_planes == 1 and sorted(m.mtype.tolist()) == [1, 2, 3]
+    assert m.camera[12] == np.float32(0.1) and m.camera[11] == np.float32(8.06)
+    a, b = pt.Scene.builtin(5, 16 / 9, 5000), pt.Scene.builtin(5, 16 / 9, 5000)   # C5 generator: deterministic
+    assert a.n_spheres == 5000 and bit_equal(a.pos_r, b.pos_r)
+    frac = np.bincount(a.mtype, minlength=4) / 5000
+    assert abs(frac[1] - 0.5) < 0.03 and abs(frac[2] - 0.4) < 0.03 and abs(frac[3] - 0.1) < 0.02
+    assert (a.pos_r[:, 1] - a.pos_r[:, 3] >= -1e-6).all()                           # above the ground plane
+
+
+def test_resolve_pack_bmp_against_oracle_and_reference_files(oracle, golden_dir, tmp_path):
+    rng = np.random.default_rng(2)
+    w, h, spp = 37, 11, 13
+    s = (rng.uniform(-0.1, 1.3, size=(h, w, 4)) * spp).astype(np.float32)
+    px = pt.resolve(s, spp)
+    assert bit_equal(px, oracle.resolve(s, spp))
+    assert (pt.pack_bgra(px) == oracle.pack_bgra(px)).all()
+    z = np.load(os.path.join(golden_dir, "scenes.npz"))
+    for head, (bw, bh) in zip(z["bmp_headers"], z["bmp_dims"]):
+        if bh < 0:
+            assert (pt.bmp_header(int(bw), int(-bh)) == head).all()
+    f = tmp_path / "out.bmp"
+    pt.bmp_write(str(f), px, w, h)
+    data = np.fromfile(f, np.uint8)
+    assert len(data) == 58 + 4 * w * h
+    assert (data[:58] == oracle.bmp_header(w, h)).all()
+    assert (data[58:].view(np.uint32) == oracle.pack_bgra(px)).all()
+    with pytest.raises(pt.PtError):
+        pt.bmp_write(str(tmp_path / "no_such_dir" / "x.bmp"), px, w, h)
+
+
+def test_product_never_touches_the_oracle():
+    """The product path must not import, link, call or read anything under oracle/ (nor /root/reference)."""
+    bad = []
+    for base in ("pathtracer_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            if os.sep + "lib" in dp:
+                continue
+            for fn in files:
+                if fn.endswith((".py", ".h", ".hip", ".cpp")):
+                    text = open(os.path.join(dp, fn), errors="replace").read()
+                    # (comments may SAY "the oracle does the same"; what must not appear is a path, module or library)
+                    if re.search(r"oracle[/.]|pyoracle|libpt_oracle|libptref|/root/reference|pt_oracle", text):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+    import subprocess
+    so = pt.LIB_PATH
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "oracle" not in needed and "ptref" not in needed

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a wave's cycles go (needs `make stamps`; never quote this build's speed, only its shares)."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pathtracer_amd as pt
+scene_id = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+w, h, spp, depth = 1920, 1080, int(sys.argv[2]) if len(sys.argv) > 2 else 64, 50
+for lib in ("libpt_hip_stamps.so", "libpt_hip.so"):
+    pt._lib = None
+    pt.load_library(os.path.join(os.path.dirname(pt.LIB_PATH), lib))
+    r = pt.Renderer(0)
+    r.upload(pt.Scene.builtin(scene_id, w / h))
+    r.render(w, h, 0, spp, depth)
+    r.render(w, h, 0, spp, depth)
+    st = r.stats()
+    tot = sum(st["phase_cycles"]) or 1
+    print(lib, json.dumps({"kernel_ms": round(st["kernel_ms"], 3), "Msamples/s": round(st["samples"] / st["kernel_ms"] / 1e3, 1),
+          "sbar": round(st["segments"] / st["samples"], 4), "lane_util": round(st["segments"] / (64 * st["wave_iterations"]), 4),
+          "iters_per_wave": round(st["wave_iterations"] / ((w // 8) * (h // 8)), 1),
+          "share_refill": round(st["phase_cycles"][0] / tot, 4), "share_hit": round(st["phase_cycles"][1] / tot, 4),
+          "share_shade": round(st["phase_cycles"][2] / tot, 4),
+          "cycles_per_iter": [round(c / max(1, st["wave_iterations"]), 1) for c in st["phase_cycles"]]}))
+    r.close()

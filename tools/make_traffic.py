@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from a tools/profile.sh run: HBM bytes per launch of k_render_lds from the PMC counters,
+corrected as MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE reads HALF the bytes
+of a wide coalesced read (x2); WRITE_SIZE is exact for 16-B-per-lane stores (our only stores)."""
+import csv, glob, json, os, sys
+d, key = sys.argv[1], sys.argv[2]
+vals = {}
+for f in glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_render" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]); write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"])
+out = {key: {"hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
+             "correction": "2*FETCH_SIZE + WRITE_SIZE, KB->B (MI355X_MICROARCH.md, HBM)"}}
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+old = json.load(open(path)) if os.path.exists(path) else {}
+old.update(out)
+json.dump(old, open(path, "w"), indent=1)
+print(json.dumps(out))

@@ -142,7 +142,7 @@ def main():
         sbar = segs / smps
         moving = scene.vel is not None
         f_sample = flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving)
-        # roofline of the dominant kernel (k_render_lds), per launch on one GPU
+        # roofline of the dominant kernel (k_render), per launch on one GPU
         achieved = (w * h * S) * f_sample / (kernel_ms * 1e-3) / 1e12
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -163,7 +163,7 @@ def main():
                        "segments_per_sample": round(sbar, 4), "kernel_ms": round(kernel_ms, 3), "lib_kernel_ms_last": round(st["kernel_ms"], 3)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "k_render_lds", "flop_per_sample": round(f_sample, 1),
+                         "kernel": "k_render", "flop_per_sample": round(f_sample, 1),
                          "note": "FP32 vector (VALU) roofline, not MFMA: BASELINE.json north_star; algorithmic FLOPs per SURVEY.md 8(d)"},
         }
         if world == 1 and args.cpu_spp > 0:

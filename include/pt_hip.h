@@ -76,8 +76,8 @@ typedef struct pt_params {
 typedef struct pt_stats {
     uint64_t samples;       /* width*height*(spp_end-spp_begin) */
     uint64_t segments;      /* loop iterations of cast_ray over all samples (S-bar = segments/samples) */
-    uint64_t sphere_tests;  /* ray-sphere evaluations (LDS kernel: segments*n_spheres; BVH kernel: leaves visited) */
-    uint64_t node_visits;   /* BVH kernel: box tests; LDS kernel: 0 */
+    uint64_t sphere_tests;  /* ray-sphere evaluations executed (LDS kernel: groups searched x 8 x 64 lanes; BVH kernel: leaf tests) */
+    uint64_t node_visits;   /* bound tests executed (LDS kernel: segments x groups; BVH kernel: box tests) */
     uint64_t wave_iterations; /* trips of the per-wave segment loop; lane utilisation = segments / (64 * wave_iterations) */
     uint64_t phase_cycles[3]; /* diagnostic builds (-DPT_STAMPS) only: shader cycles in refill / closest-hit / shading; else 0 */
     double kernel_ms;       /* HIP-event time of the render kernel on its stream */

@@ -1,0 +1,193 @@
+// pt_bvh.h -- host-side BVH builder for scenes that do not fit in LDS (C5: 10^6 spheres; the reference's scene 2).
+//
+// Takes the place of build_bvh_tree / sort_render_objects (reference src/main.cpp:93-159) -- a recursive random-axis
+// median split over an in-place quicksort with first-element pivot, one VirtualAlloc per node -- with a design of our
+// own: binned-SAH top-down build over swept boxes, iterative (explicit stack), O(N log N), leaves of up to 4 spheres,
+// nodes linearised depth-first into one array for HBM.  Topology is free: the build defines the sphere query as the
+// true closest hit, so any tree that encloses every sphere gives the same answer.
+//
+// Node = 4 x float4 = 64 B, the two CHILD boxes live in the parent so one fetch decides both children:
+//   n0 = {L.min.x, L.min.y, L.min.z, L.max.x}   n1 = {L.max.y, L.max.z, R.min.x, R.min.y}
+//   n2 = {R.min.z, R.max.x, R.max.y, R.max.z}   n3 = {bits(leftRef), bits(rightRef), 0, 0}
+//   ref: inner node -> node index; leaf -> 0x80000000 | (count-1) << 28 | first   (count <= 8, first < 2^28)
+// Spheres are re-ordered so that a leaf's spheres are contiguous: sph[i] = {cx,cy,cz,r2}, vel[i] = {vx,vy,vz,0},
+// mat[2i] = {type, roughness, n, bits(original index)}, mat[2i+1] = rgba.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <vector>
+
+#include "../../include/pt_hip.h"
+
+namespace pth {
+
+struct BvhData
+{
+    std::vector<float> nodes;  // 16 floats per node
+    std::vector<float> sph;    // 4 per sphere (sorted order)
+    std::vector<float> vel;    // 4 per sphere (empty if static)
+    std::vector<float> mat;    // 8 per sphere
+    uint32_t n_nodes = 0, n_spheres = 0, depth = 0, root_ref = 0;
+    bool moving = false;
+};
+
+struct Aabb { float lo[3], hi[3]; };
+inline void aabb_reset(Aabb& b) { for (int k = 0; k < 3; ++k) { b.lo[k] = 3.0e38f; b.hi[k] = -3.0e38f; } }
+inline void aabb_grow(Aabb& b, const Aabb& o) { for (int k = 0; k < 3; ++k) { if (o.lo[k] < b.lo[k]) b.lo[k] = o.lo[k]; if (o.hi[k] > b.hi[k]) b.hi[k] = o.hi[k]; } }
+inline float aabb_area(const Aabb& b)
+{
+    float e[3] = {b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]};
+    if (e[0] < 0) return 0.0f;
+    return 2.0f * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
+}
+inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+constexpr uint32_t kLeafMax = 4;
+constexpr uint32_t kLeafFlag = 0x80000000u;
+
+inline void build_bvh(const pt_scene_desc* d, BvhData* out)
+{
+    const uint32_t n = d->n_spheres;
+    out->n_spheres = n;
+    out->moving = false;
+    if (d->sphere_vel)
+        for (size_t i = 0; i < 3 * (size_t)n; ++i)
+            if (d->sphere_vel[i] != 0.0f) { out->moving = true; break; }
+    // swept, padded boxes: the device's slab test is ordinary f32 arithmetic, the leaf test is the reference's exact
+    // one; the pad keeps every sphere the exact test could hit inside its box.
+    std::vector<Aabb> box(n);
+    std::vector<float> cen(3 * (size_t)n);
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        const float* s = d->sphere_pos_r + 4 * (size_t)i;
+        const float r = fabsf(s[3]);
+        for (int k = 0; k < 3; ++k)
+        {
+            float a = s[k], b2 = s[k];
+            if (out->moving) { float v = d->sphere_vel[3 * (size_t)i + k]; a = s[k] + v * d->t0; b2 = s[k] + v * d->t1; }
+            float lo = (a < b2 ? a : b2) - r, hi = (a > b2 ? a : b2) + r;
+            float pad = 1e-4f * (fabsf(lo) > fabsf(hi) ? fabsf(lo) : fabsf(hi)) + 1e-4f * r + 1e-6f;
+            box[i].lo[k] = lo - pad; box[i].hi[k] = hi + pad;
+            cen[3 * (size_t)i + k] = 0.5f * (lo + hi);
+        }
+    }
+    std::vector<uint32_t> idx(n);
+    for (uint32_t i = 0; i < n; ++i) idx[i] = i;
+
+    struct Task { uint32_t begin, end, parent, side, depth; }; // parent node index, side 0 = left ref, 1 = right ref
+    std::vector<Task> stack;
+    out->nodes.clear();
+    out->depth = 0;
+    auto make_leaf_ref = [](uint32_t begin, uint32_t count) { return kLeafFlag | ((count - 1u) << 28) | begin; };
+    auto range_box = [&](uint32_t b, uint32_t e) { Aabb r; aabb_reset(r); for (uint32_t i = b; i < e; ++i) aabb_grow(r, box[idx[i]]); return r; };
+    auto set_child = [&](uint32_t parent, uint32_t side, uint32_t ref, const Aabb& bx) {
+        float* nd = out->nodes.data() + 16 * (size_t)parent;
+        if (side == 0) { nd[0] = bx.lo[0]; nd[1] = bx.lo[1]; nd[2] = bx.lo[2]; nd[3] = bx.hi[0]; nd[4] = bx.hi[1]; nd[5] = bx.hi[2]; nd[12] = u2f(ref); }
+        else { nd[6] = bx.lo[0]; nd[7] = bx.lo[1]; nd[8] = bx.lo[2]; nd[9] = bx.hi[0]; nd[10] = bx.hi[1]; nd[11] = bx.hi[2]; nd[13] = u2f(ref); }
+    };
+    if (n == 0) { out->root_ref = kLeafFlag; out->n_nodes = 0; return; } // leaf of "1 sphere at 0" is never used: n_spheres == 0 short-cuts
+    if (n <= kLeafMax) { out->root_ref = make_leaf_ref(0, n); }
+    else
+    {
+        out->nodes.resize(16, 0.0f); // root inner node = node 0
+        out->root_ref = 0;
+        stack.push_back({0, n, 0xFFFFFFFFu, 0, 1});
+        while (!stack.empty())
+        {
+            Task t = stack.back();
+            stack.pop_back();
+            if (t.depth > out->depth) out->depth = t.depth;
+            const uint32_t count = t.end - t.begin;
+            uint32_t self; // index of the inner node for this range
+            if (t.parent == 0xFFFFFFFFu) self = 0;
+            else
+            {
+                self = (uint32_t)(out->nodes.size() / 16);
+                out->nodes.resize(out->nodes.size() + 16, 0.0f);
+                set_child(t.parent, t.side, self, range_box(t.begin, t.end));
+            }
+            // binned SAH over the centroid bounds (16 bins, best of 3 axes); falls back to a median split
+            float clo[3] = {3e38f, 3e38f, 3e38f}, chi[3] = {-3e38f, -3e38f, -3e38f};
+            for (uint32_t i = t.begin; i < t.end; ++i)
+                for (int k = 0; k < 3; ++k) { float c = cen[3 * (size_t)idx[i] + k]; if (c < clo[k]) clo[k] = c; if (c > chi[k]) chi[k] = c; }
+            int bestAxis = -1, bestBin = -1; float bestCost = 3e38f;
+            const int NB = 16;
+            for (int k = 0; k < 3; ++k)
+            {
+                const float ext = chi[k] - clo[k];
+                if (!(ext > 0)) continue;
+                Aabb bb[NB]; uint32_t bc[NB];
+                for (int b2 = 0; b2 < NB; ++b2) { aabb_reset(bb[b2]); bc[b2] = 0; }
+                const float scale = NB / ext;
+                for (uint32_t i = t.begin; i < t.end; ++i)
+                {
+                    int b2 = (int)((cen[3 * (size_t)idx[i] + k] - clo[k]) * scale);
+                    if (b2 >= NB) b2 = NB - 1;
+                    if (b2 < 0) b2 = 0;
+                    aabb_grow(bb[b2], box[idx[i]]); ++bc[b2];
+                }
+                float rightArea[NB]; uint32_t rightCount[NB];
+                Aabb acc; aabb_reset(acc); uint32_t cnt = 0;
+                for (int b2 = NB - 1; b2 > 0; --b2) { aabb_grow(acc, bb[b2]); cnt += bc[b2]; rightArea[b2] = aabb_area(acc); rightCount[b2] = cnt; }
+                aabb_reset(acc); cnt = 0;
+                for (int b2 = 0; b2 < NB - 1; ++b2)
+                {
+                    aabb_grow(acc, bb[b2]); cnt += bc[b2];
+                    if (cnt == 0 || rightCount[b2 + 1] == 0) continue;
+                    float cost = aabb_area(acc) * cnt + rightArea[b2 + 1] * rightCount[b2 + 1];
+                    if (cost < bestCost) { bestCost = cost; bestAxis = k; bestBin = b2; }
+                }
+            }
+            uint32_t mid;
+            if (bestAxis >= 0)
+            {
+                const int k = bestAxis;
+                const float scale = NB / (chi[k] - clo[k]);
+                uint32_t* first = idx.data() + t.begin; uint32_t* last = idx.data() + t.end;
+                uint32_t* m = std::partition(first, last, [&](uint32_t i) {
+                    int b2 = (int)((cen[3 * (size_t)i + k] - clo[k]) * scale);
+                    if (b2 >= NB) b2 = NB - 1;
+                    if (b2 < 0) b2 = 0;
+                    return b2 <= bestBin; });
+                mid = (uint32_t)(m - idx.data());
+            }
+            else
+                mid = t.begin; // all centroids coincide
+            if (mid == t.begin || mid == t.end)
+            {
+                mid = t.begin + count / 2;
+                int k = 0; float e = -1;
+                for (int a = 0; a < 3; ++a) if (chi[a] - clo[a] > e) { e = chi[a] - clo[a]; k = a; }
+                std::nth_element(idx.begin() + t.begin, idx.begin() + mid, idx.begin() + t.end,
+                                 [&](uint32_t a, uint32_t b2) { return cen[3 * (size_t)a + k] < cen[3 * (size_t)b2 + k]; });
+            }
+            const uint32_t rng[2][2] = {{t.begin, mid}, {mid, t.end}};
+            for (int side = 1; side >= 0; --side) // push right first so the left subtree is laid out next (depth-first)
+            {
+                const uint32_t b2 = rng[side][0], e = rng[side][1];
+                if (e - b2 <= kLeafMax) set_child(self, (uint32_t)side, make_leaf_ref(b2, e - b2), range_box(b2, e));
+                else stack.push_back({b2, e, self, (uint32_t)side, t.depth + 1});
+            }
+        }
+    }
+    out->n_nodes = (uint32_t)(out->nodes.size() / 16);
+    // sphere payload in leaf order
+    out->sph.resize(4 * (size_t)n); out->mat.resize(8 * (size_t)n);
+    if (out->moving) out->vel.assign(4 * (size_t)n, 0.0f); else out->vel.clear();
+    for (uint32_t sl = 0; sl < n; ++sl)
+    {
+        const uint32_t i = idx[sl];
+        const float* s = d->sphere_pos_r + 4 * (size_t)i;
+        float* o = out->sph.data() + 4 * (size_t)sl;
+        o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3] * s[3]; // r2 as the reference forms it (geometry.cpp:47)
+        if (out->moving) { float* v = out->vel.data() + 4 * (size_t)sl; v[0] = d->sphere_vel[3 * (size_t)i]; v[1] = d->sphere_vel[3 * (size_t)i + 1]; v[2] = d->sphere_vel[3 * (size_t)i + 2]; }
+        float* m = out->mat.data() + 8 * (size_t)sl;
+        m[0] = u2f(d->sphere_mat_type[i]); m[1] = d->sphere_mat_param[2 * (size_t)i]; m[2] = d->sphere_mat_param[2 * (size_t)i + 1]; m[3] = u2f(i);
+        memcpy(m + 4, d->sphere_mat_rgba + 4 * (size_t)i, 16);
+    }
+}
+
+} // namespace pth

@@ -170,13 +170,17 @@ template <class R> PT_DEV Ray get_ray(const DeviceCamera& c, float u, float v, R
 // Blob = array of float4, identical in HBM and LDS (pt_host.cpp: build_blob):
 //   pairs   [2*npairs] : A = {cx0,cx1,cy0,cy1}  B = {cz0,cz1,r2_0,r2_1}     (two spheres per entry, SoA-of-pairs)
 //   velp    [2*npairs] : A = {vx0,vx1,vy0,vy1}  B = {vz0,vz1,0,0}           (only if the scene moves)
-//   smat    [2*ns]     : {type bits, roughness, n, 0}, {r,g,b,a}
+//   groups  [ngroups]  : bounding spheres of pairs 4g..4g+3 (8 spheres, swept over [t0,t1]), SoA-of-4:
+//                        {cx0..3},{cy0..3},{cz0..3},{R2_0..3} per four groups; ngroups is a multiple of 4
+//   smat    [2*slots]  : {type bits, roughness, n, original index bits}, {r,g,b,a}
 //   planes  [np]       : {nx,ny,nz,offset}
 //   pmat    [2*np]     : as smat
+// Spheres are stored in a spatially sorted order (slots); npairs is a multiple of 4; unused slots are spheres with
+// r2 = -1 (negative discriminant for every ray) and original index 0xFFFFFFFF.
 struct SceneView
 {
-    const float4* pairs; const float4* velp; const float4* smat; const float4* planes; const float4* pmat;
-    uint32_t ns, npairs, np; uint32_t idx_mask; // idx_mask = 2^bits-1 >= 2*npairs-1
+    const float4* pairs; const float4* velp; const float4* groups; const float4* smat; const float4* planes; const float4* pmat;
+    uint32_t ns, npairs, ngroups, np; uint32_t idx_mask; // ns = 2*npairs slots; idx_mask = 2^bits-1 >= ns-1
 };
 
 struct Material { uint32_t type; V4 colour; float roughness, n; };
@@ -186,6 +190,7 @@ PT_DEV Material load_material(const float4* m, uint32_t i)
     Material r; r.type = __float_as_uint(a.x); r.roughness = a.y; r.n = a.z; r.colour = v4(b.x, b.y, b.z, b.w);
     return r;
 }
+PT_DEV uint32_t original_index(const SceneView& s, uint32_t slot) { return __float_as_uint(s.smat[2 * slot].w); }
 
 PT_DEV void load_sphere(const SceneView& s, uint32_t i, V3* c, float* r2)
 {
@@ -229,16 +234,21 @@ PT_DEV float intersect_plane_exact(const Ray& ray, V3 n, float offset)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// The search: which sphere has the smallest t > kMinT.  Returns a sphere index to evaluate exactly, or -1.
-// Key trick: w = t - kMinT as raw bits; valid hits are positive floats, which order like unsigned integers; a
+// The search: which sphere SLOT has the smallest t > kMinT.  Returns a slot to evaluate exactly, or -1.
+//
+// Two levels.  (1) Spheres are stored spatially sorted, 8 to a group with a bounding sphere; a group is searched only
+// if the ray of at least ONE live lane of the wave can touch its bound (a wave-uniform branch on a ballot: no
+// divergence, and all lanes read the same LDS address -> broadcast).  (2) Inside a group, brute force over 4 sphere
+// pairs in packed math.
+// Key trick of (2): w = t - kMinT as raw bits; valid hits are positive floats, which order like unsigned integers; a
 // negative w (sphere behind the ray / the sphere just left) has the sign bit set and a NaN (no real root) is above
 // +inf, so ONE unsigned min does validity test and closest test.  The index rides in the low bits of the key:
 //   WIDE = false (<= 256 pairs): key = {w[31:8], pair index} by one v_perm_b32 on min(w0,w1); the two spheres of
 //                                the winning pair are then both evaluated exactly by the caller.  Ordering
 //                                resolution between DIFFERENT pairs: 2^-15 relative.
-//   WIDE = true                : key = (w & ~mask) | sphere index (v_and + v_or per sphere), resolution 2^-(23-bits).
+//   WIDE = true                : key = (w & ~mask) | slot (v_and + v_or per sphere), resolution 2^-(23-bits).
 // The resolution only matters for two spheres hit at distances that close, i.e. the seam of interpenetrating spheres.
-template <bool MOVING, bool WIDE> PT_DEV int32_t search_spheres_fast(const SceneView& s, const Ray& ray, float time)
+template <bool MOVING, bool WIDE> PT_DEV int32_t search_spheres_fast(const SceneView& s, const Ray& ray, float time, bool live, uint32_t* searched)
 {
 #pragma clang fp contract(fast)
     // Origin advanced by kMinT along the (unit) direction: the near root measured from there IS t - kMinT.
@@ -248,62 +258,192 @@ template <bool MOVING, bool WIDE> PT_DEV int32_t search_spheres_fast(const Scene
     const f32x2 tt = {time, time};
     const uint32_t keep = ~s.idx_mask;
     uint32_t best = 0x7F800000u; // +inf
-    const uint32_t np = s.npairs;
-#pragma unroll 4
-    for (uint32_t j = 0; j < np; ++j)
+    // Bounds are tested four groups at a time (SoA-of-4: {cx0..3},{cy0..3},{cz0..3},{R2_0..3}) in packed math, with
+    // the four LDS reads in flight together; then only the groups some live lane can touch are searched.
+    const uint32_t nb = s.ngroups >> 2; // ngroups is a multiple of 4 (unused bounds have R2 = -1: never touched)
+    for (uint32_t q = 0; q < nb; ++q)
     {
-        float4 A = s.pairs[2 * j], B = s.pairs[2 * j + 1];
-        f32x2 cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, r2 = {B.z, B.w};
-        if (MOVING)
+        const float4 X = s.groups[4 * q], Y = s.groups[4 * q + 1], Z = s.groups[4 * q + 2], R = s.groups[4 * q + 3];
+        uint32_t todo = 0;
         {
-            float4 VA = s.velp[2 * j], VB = s.velp[2 * j + 1];
-            f32x2 vx = {VA.x, VA.y}, vy = {VA.z, VA.w}, vz = {VB.x, VB.y};
-            cx = vx * tt + cx; cy = vy * tt + cy; cz = vz * tt + cz; // main.cpp:66
+            const f32x2 gx0 = ox - f32x2{X.x, X.y}, gy0 = oy - f32x2{Y.x, Y.y}, gz0 = oz - f32x2{Z.x, Z.y};
+            const f32x2 gx1 = ox - f32x2{X.z, X.w}, gy1 = oy - f32x2{Y.z, Y.w}, gz1 = oz - f32x2{Z.z, Z.w};
+            const f32x2 hb0 = gx0 * dx + gy0 * dy + gz0 * dz, hb1 = gx1 * dx + gy1 * dy + gz1 * dz;
+            const f32x2 cc0 = gx0 * gx0 + (gy0 * gy0 + (gz0 * gz0 - f32x2{R.x, R.y}));
+            const f32x2 cc1 = gx1 * gx1 + (gy1 * gy1 + (gz1 * gz1 - f32x2{R.z, R.w}));
+            const f32x2 ds0 = hb0 * hb0 - cc0, ds1 = hb1 * hb1 - cc1;
+            // the line meets the bound, and the bound is not wholly behind the origin
+            const bool t0 = live && ds0.x > 0.0f && !(hb0.x > 0.0f && cc0.x > 0.0f);
+            const bool t1 = live && ds0.y > 0.0f && !(hb0.y > 0.0f && cc0.y > 0.0f);
+            const bool t2 = live && ds1.x > 0.0f && !(hb1.x > 0.0f && cc1.x > 0.0f);
+            const bool t3 = live && ds1.y > 0.0f && !(hb1.y > 0.0f && cc1.y > 0.0f);
+            todo = (__ballot(t0) ? 1u : 0u) | (__ballot(t1) ? 2u : 0u) | (__ballot(t2) ? 4u : 0u) | (__ballot(t3) ? 8u : 0u);
         }
-        f32x2 ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
-        f32x2 hb = ocx * dx + ocy * dy + ocz * dz;                      // b/2
-        f32x2 c = ocx * ocx + (ocy * ocy + (ocz * ocz - r2));
-        f32x2 disc = hb * hb - c;                                       // discriminant/4
-        float w0 = -hb.x - __builtin_amdgcn_sqrtf(disc.x);              // t - kMinT; NaN when disc < 0
-        float w1 = -hb.y - __builtin_amdgcn_sqrtf(disc.y);
-        if (WIDE)
+        while (todo) // wave-uniform
         {
-            uint32_t k0 = (__float_as_uint(w0) & keep) | (2 * j);
-            uint32_t k1 = (__float_as_uint(w1) & keep) | (2 * j + 1);
-            best = min(best, min(k0, k1));
-        }
-        else
-        {
-            uint32_t m = min(__float_as_uint(w0), __float_as_uint(w1));
-            best = min(best, __builtin_amdgcn_perm(m, j, 0x07060500u)); // {m.b3, m.b2, m.b1, j.b0}
+            const uint32_t g = 4 * q + (uint32_t)__builtin_ctz(todo);
+            todo &= todo - 1u;
+            ++*searched; // groups this wave had to search
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+            {
+                const uint32_t j = 4 * g + u;
+                float4 A = s.pairs[2 * j], B = s.pairs[2 * j + 1];
+                f32x2 cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, r2 = {B.z, B.w};
+                if (MOVING)
+                {
+                    float4 VA = s.velp[2 * j], VB = s.velp[2 * j + 1];
+                    f32x2 vx = {VA.x, VA.y}, vy = {VA.z, VA.w}, vz = {VB.x, VB.y};
+                    cx = vx * tt + cx; cy = vy * tt + cy; cz = vz * tt + cz; // main.cpp:66
+                }
+                f32x2 ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+                f32x2 hb = ocx * dx + ocy * dy + ocz * dz;                      // b/2
+                f32x2 c = ocx * ocx + (ocy * ocy + (ocz * ocz - r2));
+                f32x2 disc = hb * hb - c;                                       // discriminant/4
+                float w0 = -hb.x - __builtin_amdgcn_sqrtf(disc.x);              // t - kMinT; NaN when disc < 0
+                float w1 = -hb.y - __builtin_amdgcn_sqrtf(disc.y);
+                if (WIDE)
+                {
+                    uint32_t k0 = (__float_as_uint(w0) & keep) | (2 * j);
+                    uint32_t k1 = (__float_as_uint(w1) & keep) | (2 * j + 1);
+                    best = min(best, min(k0, k1));
+                }
+                else
+                {
+                    uint32_t m = min(__float_as_uint(w0), __float_as_uint(w1));
+                    best = min(best, __builtin_amdgcn_perm(m, j, 0x07060500u)); // {m.b3, m.b2, m.b1, j.b0}
+                }
+            }
         }
     }
     if (best >= 0x7F800000u) return -1;
     return WIDE ? (int32_t)(best & s.idx_mask) : (int32_t)(2u * (best & 0xFFu));
 }
 
-// The same query in reference arithmetic for EVERY sphere: lowest index wins ties (oracle: query_closest).
+// The same query in reference arithmetic for EVERY sphere; an exact tie goes to the lowest ORIGINAL index, as in a
+// loop over the caller's sphere order.
 template <bool MOVING> PT_DEV int32_t search_spheres_strict(const SceneView& s, const Ray& ray, float time, float* tOut)
 {
     float best = kF32Max;
     int32_t obj = -1;
+    uint32_t bestOrig = 0xFFFFFFFFu;
     for (uint32_t i = 0; i < s.ns; ++i)
     {
         V3 c; float r2;
         load_sphere(s, i, &c, &r2);
         if (MOVING) c = add(c, mul(load_velocity(s, i), time));
-        float t = intersect_sphere_exact(ray, c, r2);
-        if (t > kMinT && t < best) { best = t; obj = (int32_t)i; }
+        const float t = intersect_sphere_exact(ray, c, r2);
+        const uint32_t orig = original_index(s, i);
+        if (t > kMinT && (t < best || (t == best && orig < bestOrig)) && orig != 0xFFFFFFFFu) { best = t; obj = (int32_t)i; bestOrig = orig; }
     }
     *tOut = best;
     return obj;
 }
 
+// ------------------------------------------------------------------ BVH in HBM (scenes that overflow LDS)
+// Node / payload layout: pt_bvh.h.  Per-lane traversal with a 32-entry stack in LDS (lane-strided, conflict-free),
+// near child first, boxes culled against the current closest t.  Leaf spheres are tested in the REFERENCE's arithmetic,
+// so the result is the exact closest hit (smallest t > kMinT, lowest original index on an exact tie) whatever the
+// tree looks like -- the same definition the LDS search implements.
+constexpr uint32_t kBvhLeafFlag = 0x80000000u;
+constexpr uint32_t kBvhStack = 32; // >= tree depth, guaranteed by the host builder (median fallback)
+struct BvhView
+{
+    const float4* nodes; const float4* sph; const float4* vel; const float4* mat;
+    uint32_t root_ref, n_spheres;
+};
+
+template <bool MOVING>
+PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float tLimit, uint32_t* stack /* this lane's column, stride 64 */,
+                           float* tOut, V3* centreOut, uint32_t* nodeVisits, uint32_t* sphereTests)
+{
+    float best = tLimit;               // a plane hit found earlier wins ties against spheres (main.cpp:204)
+    int32_t bestSlot = -1;
+    uint32_t bestOrig = 0xFFFFFFFFu;
+    V3 bestCentre = v3(0, 0, 0);
+    if (b.n_spheres != 0)
+    {
+        // finite reciprocals: a zero direction component must not turn (lo - o) * inv into NaN
+        const float big = 1.0e30f;
+        const float ix = fabsf(ray.d.x) > 1e-30f ? 1.0f / ray.d.x : (ray.d.x < 0 ? -big : big);
+        const float iy = fabsf(ray.d.y) > 1e-30f ? 1.0f / ray.d.y : (ray.d.y < 0 ? -big : big);
+        const float iz = fabsf(ray.d.z) > 1e-30f ? 1.0f / ray.d.z : (ray.d.z < 0 ? -big : big);
+        uint32_t sp = 0, cur = b.root_ref;
+        for (;;)
+        {
+            if (cur & kBvhLeafFlag)
+            {
+                const uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 7u) + 1u;
+                for (uint32_t k = 0; k < count; ++k)
+                {
+                    const uint32_t slot = first + k;
+                    const float4 sd = b.sph[slot];
+                    V3 c = v3(sd.x, sd.y, sd.z);
+                    if (MOVING) { const float4 vd = b.vel[slot]; c = add(c, mul(v3(vd.x, vd.y, vd.z), time)); } // main.cpp:66
+                    const float t = intersect_sphere_exact(ray, c, sd.w);
+                    ++*sphereTests;
+                    if (t > kMinT && t <= best)
+                    {
+                        const uint32_t orig = __float_as_uint(b.mat[2 * slot].w);
+                        if (t < best || (bestSlot >= 0 && orig < bestOrig)) { best = t; bestSlot = (int32_t)slot; bestOrig = orig; bestCentre = c; }
+                    }
+                }
+                if (sp == 0) break;
+                cur = stack[(--sp) * 64u];
+            }
+            else
+            {
+                const float4 n0 = b.nodes[4 * cur], n1 = b.nodes[4 * cur + 1], n2 = b.nodes[4 * cur + 2], n3 = b.nodes[4 * cur + 3];
+                ++*nodeVisits;
+                // slabs of the left box {n0.xyz .. n0.w, n1.x, n1.y} and the right box {n1.z, n1.w, n2.x .. n2.yzw}
+                float a0 = (n0.x - ray.o.x) * ix, a1 = (n0.w - ray.o.x) * ix;
+                float b0 = (n0.y - ray.o.y) * iy, b1 = (n1.x - ray.o.y) * iy;
+                float c0 = (n0.z - ray.o.z) * iz, c1 = (n1.y - ray.o.z) * iz;
+                const float nearL = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+                const float farL = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+                a0 = (n1.z - ray.o.x) * ix; a1 = (n2.y - ray.o.x) * ix;
+                b0 = (n1.w - ray.o.y) * iy; b1 = (n2.z - ray.o.y) * iy;
+                c0 = (n2.x - ray.o.z) * iz; c1 = (n2.w - ray.o.z) * iz;
+                const float nearR = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+                const float farR = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+                const bool hitL = farL >= fmaxf(nearL, 0.0f) && nearL <= best;
+                const bool hitR = farR >= fmaxf(nearR, 0.0f) && nearR <= best;
+                const uint32_t refL = __float_as_uint(n3.x), refR = __float_as_uint(n3.y);
+                if (hitL && hitR)
+                {
+                    const bool leftFirst = nearL <= nearR;
+                    stack[(sp++) * 64u] = leftFirst ? refR : refL;
+                    cur = leftFirst ? refL : refR;
+                }
+                else if (hitL) cur = refL;
+                else if (hitR) cur = refR;
+                else
+                {
+                    if (sp == 0) break;
+                    cur = stack[(--sp) * 64u];
+                }
+            }
+        }
+    }
+    *tOut = best;
+    *centreOut = bestCentre;
+    return bestSlot;
+}
+
 struct Hit { float t; int32_t prim; V3 point, normal; Material m; };
 
-// First half of cast_ray (main.cpp:180-216): planes linearly, then the sphere query; closest wins, planes win ties.
-template <bool MOVING, bool STRICT> PT_DEV Hit closest_hit(const SceneView& s, const Ray& ray, float time)
+// How the sphere query is answered.
+enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2 };
+struct QueryCtx // per-lane scratch and counters of the sphere query
 {
+    BvhView bvh; uint32_t* stack; uint32_t searched, nodeVisits, sphereTests;
+};
+
+// First half of cast_ray (main.cpp:180-216): planes linearly, then the sphere query; closest wins, planes win ties.
+template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, const Ray& ray, float time, bool live, QueryCtx& q)
+{
+    constexpr bool STRICT = MODE == MODE_LDS_STRICT;
+    uint32_t* searched = &q.searched;
     Hit h;
     h.t = kF32Max; h.prim = kPrimMiss; h.point = v3(0, 0, 0); h.normal = v3(0, 0, 0);
     h.m.type = MAT_NONE; h.m.colour = v4(0, 0, 0, 0); h.m.roughness = 0; h.m.n = 0;
@@ -317,7 +457,14 @@ template <bool MOVING, bool STRICT> PT_DEV Hit closest_hit(const SceneView& s, c
     int32_t obj;
     float t = kF32Max;
     V3 centre = v3(0, 0, 0);
-    if (STRICT)
+    Material sphereMat; sphereMat.type = MAT_NONE; sphereMat.colour = v4(0, 0, 0, 0); sphereMat.roughness = 0; sphereMat.n = 0;
+    uint32_t origIndex = 0;
+    if (MODE == MODE_BVH)
+    {
+        obj = bvh_closest<MOVING>(q.bvh, ray, time, h.t, q.stack, &t, &centre, &q.nodeVisits, &q.sphereTests);
+        if (obj >= 0) { sphereMat = load_material(q.bvh.mat, (uint32_t)obj); origIndex = __float_as_uint(q.bvh.mat[2 * (uint32_t)obj].w); }
+    }
+    else if (STRICT)
     {
         obj = search_spheres_strict<MOVING>(s, ray, time, &t);
         if (obj >= 0)
@@ -331,12 +478,12 @@ template <bool MOVING, bool STRICT> PT_DEV Hit closest_hit(const SceneView& s, c
         // The winner (or the winning pair) is re-evaluated in reference arithmetic; lower index wins an exact tie.
         if (s.npairs <= 256u)
         {
-            obj = search_spheres_fast<MOVING, false>(s, ray, time);
+            obj = search_spheres_fast<MOVING, false>(s, ray, time, live, searched);
             if (obj >= 0)
             {
                 V3 c0, c1; float r20, r21;
                 load_sphere(s, (uint32_t)obj, &c0, &r20);
-                load_sphere(s, (uint32_t)obj + 1u, &c1, &r21);       // the odd slot of an odd scene has r2 = -1: never hit
+                load_sphere(s, (uint32_t)obj + 1u, &c1, &r21);       // an unused slot has r2 = -1: never hit
                 if (MOVING)
                 {
                     c0 = add(c0, mul(load_velocity(s, (uint32_t)obj), time));
@@ -344,7 +491,8 @@ template <bool MOVING, bool STRICT> PT_DEV Hit closest_hit(const SceneView& s, c
                 }
                 const float t0 = intersect_sphere_exact(ray, c0, r20), t1 = intersect_sphere_exact(ray, c1, r21);
                 const bool v0 = t0 > kMinT, v1 = t1 > kMinT;
-                const bool second = v1 && (!v0 || t1 < t0);
+                const bool second = v1 && (!v0 || t1 < t0 ||
+                                           (t1 == t0 && original_index(s, (uint32_t)obj + 1u) < original_index(s, (uint32_t)obj)));
                 t = second ? t1 : t0;
                 centre = second ? c1 : c0;
                 obj = second ? obj + 1 : obj;
@@ -352,7 +500,7 @@ template <bool MOVING, bool STRICT> PT_DEV Hit closest_hit(const SceneView& s, c
         }
         else
         {
-            obj = search_spheres_fast<MOVING, true>(s, ray, time);
+            obj = search_spheres_fast<MOVING, true>(s, ray, time, live, searched);
             if (obj >= 0)
             {
                 float r2; load_sphere(s, (uint32_t)obj, &centre, &r2);
@@ -361,12 +509,13 @@ template <bool MOVING, bool STRICT> PT_DEV Hit closest_hit(const SceneView& s, c
             }
         }
     }
+    if (MODE != MODE_BVH && obj >= 0) { sphereMat = load_material(s.smat, (uint32_t)obj); origIndex = original_index(s, (uint32_t)obj); }
     if (obj >= 0 && t > kMinT && t < h.t)                                // main.cpp:204-216
     {
-        h.t = t; h.prim = obj;
+        h.t = t; h.prim = (int32_t)origIndex;
         h.point = ray_at(ray, t);
         h.normal = normalize(sub(h.point, centre));
-        h.m = load_material(s.smat, (uint32_t)obj);
+        h.m = sphereMat;
     }
     else if (planeIdx >= 0)
     {
@@ -479,23 +628,23 @@ PT_DEV bool shade_step(Ray& ray, const Hit& h, V4& throughput, R& rng, V4* termi
     *terminal = sky(ray);
     return false;
 }
-template <bool MOVING, bool STRICT, class R>
-PT_DEV bool path_step(const SceneView& s, Ray& ray, float time, V4& throughput, R& rng, V4* terminal)
+template <bool MOVING, int MODE, class R>
+PT_DEV bool path_step(const SceneView& s, QueryCtx& q, Ray& ray, float time, V4& throughput, R& rng, V4* terminal)
 {
-    const Hit h = closest_hit<MOVING, STRICT>(s, ray, time);
+    const Hit h = closest_hit<MOVING, MODE>(s, ray, time, true, q);
     return shade_step(ray, h, throughput, rng, terminal);
 }
 
 // cast_ray (main.cpp:171-307) as a loop, for the probes.
-template <bool MOVING, bool STRICT, class R>
-PT_DEV V4 cast_ray(const SceneView& s, Ray ray, uint32_t maxDepth, float time, R& rng, uint32_t* segments)
+template <bool MOVING, int MODE, class R>
+PT_DEV V4 cast_ray(const SceneView& s, QueryCtx& q, Ray ray, uint32_t maxDepth, float time, R& rng, uint32_t* segments)
 {
     V4 T = v4(1, 1, 1, 1), terminal = v4(0, 0, 0, 1);
     uint32_t n = 0;
     for (uint32_t depth = maxDepth; depth != 0; --depth)                 // depth 0 -> BLACK (main.cpp:175-176)
     {
         ++n;
-        if (!path_step<MOVING, STRICT>(s, ray, time, T, rng, &terminal)) break;
+        if (!path_step<MOVING, MODE>(s, q, ray, time, T, rng, &terminal)) break;
         terminal = v4(0, 0, 0, 1);
     }
     *segments = n;

@@ -1,7 +1,7 @@
 // pt_hip.hip -- kernels and C-ABI of libpt_hip.so (gfx950 only; see include/pt_hip.h for the boundary).
 //
 // Kernels
-//   k_render_lds<MOVING,STRICT>  the hot path: one wave = one 8x8 pixel tile x all samples of the call; lanes pull
+//   k_render<MOVING,STRICT>  the hot path: one wave = one 8x8 pixel tile x all samples of the call; lanes pull
 //                                (pixel, sample) work items from a wave-local pool so that a lane whose path ended
 //                                starts its next sample in the same iteration (path regeneration); the scene is
 //                                staged once per workgroup into LDS and searched by brute force.
@@ -21,6 +21,7 @@
 #include "../../include/pt_hip.h"
 #include "pt_device.h"
 #include "pt_host.h"
+#include "pt_bvh.h"
 
 using namespace ptd;
 
@@ -29,17 +30,28 @@ struct SceneArgs
 {
     const float4* blob; // HBM copy of the LDS image
     uint32_t blob_f4;   // its length in float4
-    uint32_t off_velp, off_smat, off_planes, off_pmat;
-    uint32_t ns, npairs, np, idx_mask;
+    uint32_t off_velp, off_groups, off_smat, off_planes, off_pmat;
+    uint32_t ns, npairs, ngroups, np, idx_mask;
     float t0, t1;
     DeviceCamera cam;
+    BvhView bvh;        // MODE_BVH only: nodes / spheres / materials in HBM
 };
+
+// LDS carve-up behind the blob: per wave, [64 pixels x rgba] accumulators (render kernel) and, in MODE_BVH, a
+// 32 x 64 traversal stack.
+__device__ __forceinline__ QueryCtx make_query(const SceneArgs& a, uint32_t* stackBase)
+{
+    QueryCtx q;
+    q.bvh = a.bvh; q.stack = stackBase; q.searched = 0; q.nodeVisits = 0; q.sphereTests = 0;
+    return q;
+}
 
 __device__ __forceinline__ SceneView make_view(const float4* base, const SceneArgs& a)
 {
     SceneView s;
-    s.pairs = base; s.velp = base + a.off_velp; s.smat = base + a.off_smat; s.planes = base + a.off_planes; s.pmat = base + a.off_pmat;
-    s.ns = a.ns; s.npairs = a.npairs; s.np = a.np; s.idx_mask = a.idx_mask;
+    s.pairs = base; s.velp = base + a.off_velp; s.groups = base + a.off_groups; s.smat = base + a.off_smat;
+    s.planes = base + a.off_planes; s.pmat = base + a.off_pmat;
+    s.ns = a.ns; s.npairs = a.npairs; s.ngroups = a.ngroups; s.np = a.np; s.idx_mask = a.idx_mask;
     return s;
 }
 
@@ -58,20 +70,23 @@ struct RenderArgs
     unsigned long long* stats;      // [0] segments
 };
 
-constexpr uint32_t kWavesPerBlock = 4;
+constexpr uint32_t kWavesPerBlock = 4;     // LDS modes: four waves share one staged copy of the scene
+constexpr uint32_t kWavesPerBlockBvh = 1;  // BVH mode: one wave per workgroup, so that LDS (8 KB of stack per wave) packs tightly
 
 // ================================================================================================ the hot kernel
-template <bool MOVING, bool STRICT>
-__global__ void __launch_bounds__(256) k_render_lds(RenderArgs a)
+template <bool MOVING, int MODE>
+__global__ void __launch_bounds__(256) k_render(RenderArgs a)
 {
     extern __shared__ float4 smem[];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     stage_scene(smem, a.sc);
     float* acc = reinterpret_cast<float*>(smem + a.sc.blob_f4) + wave * 256u; // [64 pixels][rgba] of this wave's tile
     acc[lane] = 0.0f; acc[lane + 64] = 0.0f; acc[lane + 128] = 0.0f; acc[lane + 192] = 0.0f;
+    uint32_t* stack = reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4 + nwaves * 64u) + wave * (kBvhStack * 64u) + lane;
+    QueryCtx qc = make_query(a.sc, stack);
     __syncthreads();
 
-    const uint32_t slot = blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t slot = blockIdx.x * nwaves + wave;
     if (slot >= a.ntiles) return;
     // Neighbouring tiles cost alike (sky rows are cheap, the sphere field is not): a multiplicative shuffle of the
     // tile order mixes cheap and expensive tiles over the whole launch, so the tail is one tile, not one region.
@@ -138,7 +153,7 @@ __global__ void __launch_bounds__(256) k_render_lds(RenderArgs a)
         ++iters;
         PT_STAMP(ts1);
         Ray ray; ray.o = v3(rox, roy, roz); ray.d = v3(rdx, rdy, rdz);
-        const Hit h = closest_hit<MOVING, STRICT>(s, ray, time);
+        const Hit h = closest_hit<MOVING, MODE>(s, ray, time, alive, qc);
         PT_STAMP(ts2);
         if (alive)
         {
@@ -172,11 +187,17 @@ __global__ void __launch_bounds__(256) k_render_lds(RenderArgs a)
         }
     }
     // ---- statistics: segments of this wave
+    if (MODE == MODE_BVH)
+    {
+        for (int o = 32; o > 0; o >>= 1) { qc.nodeVisits += __shfl_xor(qc.nodeVisits, o); qc.sphereTests += __shfl_xor(qc.sphereTests, o); }
+        if (lane == 0) { atomicAdd(a.stats + 6, (unsigned long long)qc.nodeVisits); atomicAdd(a.stats + 7, (unsigned long long)qc.sphereTests); }
+    }
     for (int o = 32; o > 0; o >>= 1) segs += __shfl_xor(segs, o);
     if (lane == 0)
     {
         atomicAdd(a.stats, (unsigned long long)segs);
         atomicAdd(a.stats + 1, (unsigned long long)iters);
+        atomicAdd(a.stats + 5, (unsigned long long)qc.searched);
 #ifdef PT_STAMPS
         atomicAdd(a.stats + 2, cyc_refill); atomicAdd(a.stats + 3, cyc_hit); atomicAdd(a.stats + 4, cyc_shade);
 #endif
@@ -185,16 +206,17 @@ __global__ void __launch_bounds__(256) k_render_lds(RenderArgs a)
 
 // ================================================================================================ probes
 struct ProbeHitsArgs { SceneArgs sc; uint32_t n; const float* rays; const float* times; float* t; int32_t* prim; float* point; float* normal; };
-template <bool MOVING, bool STRICT> __global__ void __launch_bounds__(256) k_probe_hits(ProbeHitsArgs a)
+template <bool MOVING, int MODE> __global__ void __launch_bounds__(256) k_probe_hits(ProbeHitsArgs a)
 {
     extern __shared__ float4 smem[];
     stage_scene(smem, a.sc);
+    QueryCtx qc = make_query(a.sc, reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4) + (threadIdx.x >> 6) * (kBvhStack * 64u) + (threadIdx.x & 63u));
     __syncthreads();
     const SceneView s = make_view(smem, a.sc);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     Ray r; r.o = v3(a.rays[6*i], a.rays[6*i+1], a.rays[6*i+2]); r.d = v3(a.rays[6*i+3], a.rays[6*i+4], a.rays[6*i+5]);
-    Hit h = closest_hit<MOVING, STRICT>(s, r, a.times[i]);
+    Hit h = closest_hit<MOVING, MODE>(s, r, a.times[i], true, qc);
     a.t[i] = h.t; a.prim[i] = h.prim;
     a.point[3*i] = h.point.x; a.point[3*i+1] = h.point.y; a.point[3*i+2] = h.point.z;
     a.normal[3*i] = h.normal.x; a.normal[3*i+1] = h.normal.y; a.normal[3*i+2] = h.normal.z;
@@ -246,10 +268,11 @@ struct ProbePathsArgs
     SceneArgs sc; uint32_t n, max_depth; const float* rays; const float* times;
     const float* tape32; const unsigned long long* ofs32; const double* tape64; const unsigned long long* ofs64; float* rgba; uint32_t* segs;
 };
-template <bool MOVING, bool STRICT> __global__ void __launch_bounds__(256) k_probe_paths(ProbePathsArgs a)
+template <bool MOVING, int MODE> __global__ void __launch_bounds__(256) k_probe_paths(ProbePathsArgs a)
 {
     extern __shared__ float4 smem[];
     stage_scene(smem, a.sc);
+    QueryCtx qc = make_query(a.sc, reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4) + (threadIdx.x >> 6) * (kBvhStack * 64u) + (threadIdx.x & 63u));
     __syncthreads();
     const SceneView s = make_view(smem, a.sc);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,16 +280,17 @@ template <bool MOVING, bool STRICT> __global__ void __launch_bounds__(256) k_pro
     Ray r; r.o = v3(a.rays[6*i], a.rays[6*i+1], a.rays[6*i+2]); r.d = v3(a.rays[6*i+3], a.rays[6*i+4], a.rays[6*i+5]);
     TapeRng rng; rng.init(a.tape32 + a.ofs32[i], (uint32_t)(a.ofs32[i+1] - a.ofs32[i]), a.tape64 + a.ofs64[i], (uint32_t)(a.ofs64[i+1] - a.ofs64[i]));
     uint32_t n = 0;
-    V4 c = cast_ray<MOVING, STRICT>(s, r, a.max_depth, a.times[i], rng, &n);
+    V4 c = cast_ray<MOVING, MODE>(s, qc, r, a.max_depth, a.times[i], rng, &n);
     a.rgba[4*i] = c.x; a.rgba[4*i+1] = c.y; a.rgba[4*i+2] = c.z; a.rgba[4*i+3] = c.w;
     if (a.segs) a.segs[i] = n | (rng.overrun() ? 0x80000000u : 0u);
 }
 
 struct ProbeSamplesArgs { SceneArgs sc; uint32_t n, width, height, max_depth; uint64_t seed; const uint32_t* pixels; const uint32_t* samples; float* rgba; uint32_t* segs; };
-template <bool MOVING, bool STRICT> __global__ void __launch_bounds__(256) k_probe_samples(ProbeSamplesArgs a)
+template <bool MOVING, int MODE> __global__ void __launch_bounds__(256) k_probe_samples(ProbeSamplesArgs a)
 {
     extern __shared__ float4 smem[];
     stage_scene(smem, a.sc);
+    QueryCtx qc = make_query(a.sc, reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4) + (threadIdx.x >> 6) * (kBvhStack * 64u) + (threadIdx.x & 63u));
     __syncthreads();
     const SceneView s = make_view(smem, a.sc);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -276,7 +300,7 @@ template <bool MOVING, bool STRICT> __global__ void __launch_bounds__(256) k_pro
     float time;
     Ray r = begin_sample(a.sc.cam, pixel % a.width, pixel / a.width, a.width, a.height, a.sc.t0, a.sc.t1, rng, &time);
     uint32_t n = 0;
-    V4 c = cast_ray<MOVING, STRICT>(s, r, a.max_depth, time, rng, &n);
+    V4 c = cast_ray<MOVING, MODE>(s, qc, r, a.max_depth, time, rng, &n);
     a.rgba[4*i] = c.x; a.rgba[4*i+1] = c.y; a.rgba[4*i+2] = c.z; a.rgba[4*i+3] = c.w;
     if (a.segs) a.segs[i] = n;
 }
@@ -311,14 +335,18 @@ struct pt_ctx
 {
     int device = -1;
     std::string err;
-    pth::Blob blob;          // host image of the scene blob + offsets
-    bool has_scene = false;
-    float4* blob_dev = nullptr;
-    SceneArgs sc{};
+    bool has_scene = false, moving = false, lds_ok = false;
+    // LDS mode: the whole scene as one blob; BVH mode: planes-only blob + tree and payload in HBM
+    pth::Blob blob, blob_planes;
+    float4* blob_dev = nullptr; float4* blob_planes_dev = nullptr;
+    float4* nodes_dev = nullptr; float4* sph_dev = nullptr; float4* vel_dev = nullptr; float4* mat_dev = nullptr;
+    uint32_t bvh_nodes = 0, bvh_depth = 0;
+    SceneArgs sc_lds{}, sc_bvh{};
     float* accum_dev = nullptr; size_t accum_floats = 0;
     unsigned long long* stats_dev = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    int last_mode = MODE_LDS_FAST;
     pt_stats last{};
     size_t lds_limit = 0;
 };
@@ -341,10 +369,8 @@ struct Bind // make the context's device current for the duration of a call
     ~Bind() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-constexpr size_t kMaxLdsBytes = 128 * 1024; // of the 160 KiB per CU; leaves room for a second workgroup on small scenes
-
-size_t lds_bytes_render(const SceneArgs& sc) { return (size_t)sc.blob_f4 * 16 + kWavesPerBlock * 64 * 16; }
-size_t lds_bytes_probe(const SceneArgs& sc) { return (size_t)sc.blob_f4 * 16; }
+constexpr size_t kMaxLdsBytes = 128 * 1024; // of the 160 KiB per CU
+constexpr size_t kAccBytesPerWave = 64 * 16, kStackBytesPerWave = kBvhStack * 64 * 4;
 
 uint32_t pick_stride(uint32_t ntiles)
 {
@@ -371,6 +397,36 @@ int check_scene(pt_ctx* ctx)
     return PT_OK;
 }
 
+// Which kernel family answers the sphere query for this call, and with which scene arguments.
+// waves = waves per workgroup of the kernel about to be launched; acc = it needs the per-wave tile accumulators.
+int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode, const SceneArgs** sc, size_t* lds)
+{
+    const bool wantBvh = (flags & PT_FLAG_FORCE_BVH) != 0 || !ctx->lds_ok;
+    if (wantBvh && (flags & PT_FLAG_FORCE_LDS)) return PT_ERR_UNSUPPORTED;
+    if (wantBvh)
+    {
+        *mode = MODE_BVH; *sc = &ctx->sc_bvh;
+        *lds = (size_t)ctx->sc_bvh.blob_f4 * 16 + waves * ((acc ? kAccBytesPerWave : 0) + kStackBytesPerWave);
+    }
+    else
+    {
+        *mode = (flags & PT_FLAG_STRICT_SEARCH) ? MODE_LDS_STRICT : MODE_LDS_FAST; *sc = &ctx->sc_lds;
+        *lds = (size_t)ctx->sc_lds.blob_f4 * 16 + waves * (acc ? kAccBytesPerWave : 0);
+    }
+    if (*lds > ctx->lds_limit) return PT_ERR_UNSUPPORTED;
+    return PT_OK;
+}
+
+// Launch KERNEL<moving, mode> with dynamic LDS `lds` on `stream`.
+#define PT_LAUNCH(KERNEL, moving, mode, grid, block, lds, stream, args)                                           \
+    do {                                                                                                        \
+        int st_ = PT_OK;                                                                                        \
+        auto go_ = [&](auto kern) { st_ = set_lds(ctx, kern, lds); if (st_ == PT_OK) hipLaunchKernelGGL(kern, grid, block, lds, stream, args); }; \
+        if (moving) { if (mode == MODE_BVH) go_(KERNEL<true, MODE_BVH>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<true, MODE_LDS_STRICT>); else go_(KERNEL<true, MODE_LDS_FAST>); } \
+        else        { if (mode == MODE_BVH) go_(KERNEL<false, MODE_BVH>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<false, MODE_LDS_STRICT>); else go_(KERNEL<false, MODE_LDS_FAST>); } \
+        if (st_ != PT_OK) return st_;                                                                           \
+    } while (0)
+
 // device scratch that frees itself
 struct DevBuf
 {
@@ -379,6 +435,29 @@ struct DevBuf
     hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
+
+void free_scene(pt_ctx* c)
+{
+    float4** ptrs[] = {&c->blob_dev, &c->blob_planes_dev, &c->nodes_dev, &c->sph_dev, &c->vel_dev, &c->mat_dev};
+    for (float4** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    c->has_scene = false;
+}
+
+int upload_f4(pt_ctx* ctx, const void* host, size_t bytes, float4** dev)
+{
+    HIPCHK(ctx, hipMalloc((void**)dev, bytes ? bytes : 16));
+    if (bytes) HIPCHK(ctx, hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+void fill_scene_args(SceneArgs* sc, const pth::Blob& b, const float4* dev, const pt_scene_desc* d, uint32_t np)
+{
+    sc->blob = dev; sc->blob_f4 = (uint32_t)b.f4.size();
+    sc->off_velp = b.off_velp; sc->off_groups = b.off_groups; sc->off_smat = b.off_smat; sc->off_planes = b.off_planes; sc->off_pmat = b.off_pmat;
+    sc->ns = 2 * b.npairs; sc->npairs = b.npairs; sc->ngroups = b.ngroups; sc->np = np; sc->idx_mask = b.idx_mask;
+    sc->t0 = d->t0; sc->t1 = d->t1;
+    pth::make_device_camera(d->camera, &sc->cam);
+}
 
 } // namespace
 
@@ -443,7 +522,7 @@ void pt_hip_destroy(pt_ctx* c)
 {
     if (!c) return;
     Bind b(c);
-    if (c->blob_dev) (void)hipFree(c->blob_dev);
+    free_scene(c);
     if (c->accum_dev) (void)hipFree(c->accum_dev);
     if (c->stats_dev) (void)hipFree(c->stats_dev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -457,18 +536,41 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
     int st = pth::validate_desc(d);
     if (st != PT_OK) return st;
     Bind b(ctx);
-    pth::build_blob(d, &ctx->blob);
-    if (ctx->blob_dev) { (void)hipFree(ctx->blob_dev); ctx->blob_dev = nullptr; }
-    ctx->has_scene = false;
-    const size_t bytes = ctx->blob.f4.size() * sizeof(float4);
-    HIPCHK(ctx, hipMalloc((void**)&ctx->blob_dev, bytes ? bytes : 16));
-    HIPCHK(ctx, hipMemcpy(ctx->blob_dev, ctx->blob.f4.data(), bytes, hipMemcpyHostToDevice));
-    SceneArgs& sc = ctx->sc;
-    sc.blob = ctx->blob_dev; sc.blob_f4 = (uint32_t)ctx->blob.f4.size();
-    sc.off_velp = ctx->blob.off_velp; sc.off_smat = ctx->blob.off_smat; sc.off_planes = ctx->blob.off_planes; sc.off_pmat = ctx->blob.off_pmat;
-    sc.ns = d->n_spheres; sc.npairs = ctx->blob.npairs; sc.np = d->n_planes; sc.idx_mask = ctx->blob.idx_mask;
-    sc.t0 = d->t0; sc.t1 = d->t1;
-    pth::make_device_camera(d->camera, &sc.cam);
+    free_scene(ctx);
+    // (1) LDS image of the whole scene, if it can fit beside the accumulators of a 4-wave workgroup
+    const size_t roughBytes = (size_t)d->n_spheres * (16 + 16 + 32 + 2) + (size_t)d->n_planes * 48 + 4096;
+    ctx->lds_ok = false;
+    if (roughBytes <= ctx->lds_limit)
+    {
+        pth::build_blob(d, &ctx->blob);
+        ctx->lds_ok = ctx->blob.f4.size() * 16 + kWavesPerBlock * kAccBytesPerWave <= ctx->lds_limit;
+    }
+    if (ctx->lds_ok)
+    {
+        st = upload_f4(ctx, ctx->blob.f4.data(), ctx->blob.f4.size() * 16, &ctx->blob_dev);
+        if (st != PT_OK) return st;
+        fill_scene_args(&ctx->sc_lds, ctx->blob, ctx->blob_dev, d, d->n_planes);
+        ctx->sc_lds.bvh = BvhView{};
+        ctx->moving = ctx->blob.moving;
+    }
+    // (2) BVH in HBM (always built: it is what PT_FLAG_FORCE_BVH and every scene beyond LDS use) + planes-only LDS image
+    {
+        pth::BvhData bv;
+        pth::build_bvh(d, &bv);
+        pt_scene_desc planesOnly = *d;
+        planesOnly.n_spheres = 0;
+        pth::build_blob(&planesOnly, &ctx->blob_planes);
+        st = upload_f4(ctx, ctx->blob_planes.f4.data(), ctx->blob_planes.f4.size() * 16, &ctx->blob_planes_dev); if (st != PT_OK) return st;
+        st = upload_f4(ctx, bv.nodes.data(), bv.nodes.size() * 4, &ctx->nodes_dev); if (st != PT_OK) return st;
+        st = upload_f4(ctx, bv.sph.data(), bv.sph.size() * 4, &ctx->sph_dev); if (st != PT_OK) return st;
+        st = upload_f4(ctx, bv.vel.data(), bv.vel.size() * 4, &ctx->vel_dev); if (st != PT_OK) return st;
+        st = upload_f4(ctx, bv.mat.data(), bv.mat.size() * 4, &ctx->mat_dev); if (st != PT_OK) return st;
+        fill_scene_args(&ctx->sc_bvh, ctx->blob_planes, ctx->blob_planes_dev, d, d->n_planes);
+        ctx->sc_bvh.bvh = BvhView{ctx->nodes_dev, ctx->sph_dev, ctx->vel_dev, ctx->mat_dev, bv.root_ref, bv.n_spheres};
+        ctx->bvh_nodes = bv.n_nodes; ctx->bvh_depth = bv.depth;
+        ctx->moving = bv.moving;
+        if (bv.depth >= kBvhStack) { ctx->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
+    }
     ctx->has_scene = true;
     return PT_OK;
 }
@@ -479,38 +581,32 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     if (st != PT_OK) return st;
     if (!p || !accum_dev || p->width == 0 || p->height == 0 || p->spp_end <= p->spp_begin) return PT_ERR_INVALID;
     if ((uint64_t)p->width * p->height > 0xFFFFFFFFull || (uint64_t)(p->spp_end - p->spp_begin) * 64ull > 0xFFFFFFFFull) return PT_ERR_INVALID;
-    if (p->flags & PT_FLAG_FORCE_BVH) return PT_ERR_UNSUPPORTED;
     Bind b(ctx);
     hipStream_t stream = (hipStream_t)stream_;
+    int mode; const SceneArgs* sc; size_t lds;
+    const bool bvh = (p->flags & PT_FLAG_FORCE_BVH) != 0 || !ctx->lds_ok;
+    const uint32_t waves = bvh ? kWavesPerBlockBvh : kWavesPerBlock;
+    st = select_mode(ctx, p->flags, waves, true, &mode, &sc, &lds);
+    if (st != PT_OK) return st;
     RenderArgs a{};
-    a.sc = ctx->sc;
+    a.sc = *sc;
     a.width = p->width; a.height = p->height;
     a.tiles_x = (p->width + 7) / 8;
     a.ntiles = a.tiles_x * ((p->height + 7) / 8);
     a.tile_stride = pick_stride(a.ntiles);
     a.spp_begin = p->spp_begin; a.nspp = p->spp_end - p->spp_begin; a.max_depth = p->max_depth; a.seed = p->seed;
     a.out_sum = accum_dev; a.stats = ctx->stats_dev;
-    const size_t lds = lds_bytes_render(a.sc);
-    if (lds > ctx->lds_limit) return PT_ERR_UNSUPPORTED; // BVH-in-HBM kernel: not in this build yet (scope)
-    const bool moving = ctx->blob.moving, strict = (p->flags & PT_FLAG_STRICT_SEARCH) != 0;
-    const dim3 grid((a.ntiles + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+    const dim3 grid((a.ntiles + waves - 1) / waves), block(64 * waves);
     HIPCHK(ctx, hipMemsetAsync(ctx->stats_dev, 0, 8 * sizeof(unsigned long long), stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
-#define LAUNCH_RENDER(M, S)                                                              \
-    do {                                                                                 \
-        st = set_lds(ctx, k_render_lds<M, S>, lds);                                      \
-        if (st != PT_OK) return st;                                                      \
-        hipLaunchKernelGGL((k_render_lds<M, S>), grid, block, lds, stream, a);           \
-    } while (0)
-    if (moving) { if (strict) LAUNCH_RENDER(true, true); else LAUNCH_RENDER(true, false); }
-    else        { if (strict) LAUNCH_RENDER(false, true); else LAUNCH_RENDER(false, false); }
-#undef LAUNCH_RENDER
+    PT_LAUNCH(k_render, ctx->moving, mode, grid, block, lds, stream, a);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
+    ctx->last_mode = mode;
     ctx->last = pt_stats{};
     ctx->last.samples = (uint64_t)p->width * p->height * a.nspp;
-    ctx->last.kernel = 0;
+    ctx->last.kernel = mode == MODE_BVH ? 1u : 0u;
     return PT_OK;
 }
 
@@ -545,10 +641,18 @@ int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out)
     HIPCHK(ctx, hipMemcpy(st, ctx->stats_dev, sizeof(st), hipMemcpyDeviceToHost));
     ctx->last.kernel_ms = ms;
     ctx->last.segments = st[0];
-    ctx->last.sphere_tests = st[0] * (uint64_t)ctx->sc.ns;
-    ctx->last.node_visits = 0;
     ctx->last.wave_iterations = st[1];
     ctx->last.phase_cycles[0] = st[2]; ctx->last.phase_cycles[1] = st[3]; ctx->last.phase_cycles[2] = st[4];
+    if (ctx->last_mode == MODE_BVH)
+    {
+        ctx->last.node_visits = st[6];   // inner nodes fetched (two box tests each)
+        ctx->last.sphere_tests = st[7];  // exact leaf tests
+    }
+    else
+    {
+        ctx->last.sphere_tests = st[5] * 8ull * 64ull;                          // wave-level group searches x 8 slots x 64 lanes
+        ctx->last.node_visits = st[1] * 64ull * (uint64_t)ctx->sc_lds.ngroups;   // bound tests: every lane, every group, every trip
+    }
     *out = ctx->last;
     return PT_OK;
 }
@@ -567,37 +671,6 @@ int pt_hip_resolve_device(pt_ctx* ctx, const float* accum_dev, uint32_t n_pixels
 }
 
 // ------------------------------------------------------------------------------------------------ probes
-int pt_hip_probe_hits(pt_ctx* ctx, uint32_t n, const float* rays, const float* times, uint32_t flags,
-                      float* out_t, int32_t* out_prim, float* out_point, float* out_normal)
-{
-    int st = check_scene(ctx);
-    if (st != PT_OK) return st;
-    if (!rays || !times || !out_t || !out_prim || !out_point || !out_normal) return PT_ERR_INVALID;
-    if (n == 0) return PT_OK;
-    Bind b(ctx);
-    const size_t lds = lds_bytes_probe(ctx->sc);
-    if (lds > ctx->lds_limit) return PT_ERR_UNSUPPORTED;
-    DevBuf dr, dt, ot, op, opt, on;
-    HIPCHK(ctx, dr.alloc(n * 24ull)); HIPCHK(ctx, dt.alloc(n * 4ull)); HIPCHK(ctx, ot.alloc(n * 4ull));
-    HIPCHK(ctx, op.alloc(n * 4ull)); HIPCHK(ctx, opt.alloc(n * 12ull)); HIPCHK(ctx, on.alloc(n * 12ull));
-    HIPCHK(ctx, hipMemcpy(dr.p, rays, n * 24ull, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(dt.p, times, n * 4ull, hipMemcpyHostToDevice));
-    ProbeHitsArgs a{ctx->sc, n, dr.as<float>(), dt.as<float>(), ot.as<float>(), op.as<int32_t>(), opt.as<float>(), on.as<float>()};
-    const dim3 grid((n + 255) / 256), block(256);
-    const bool moving = ctx->blob.moving, strict = (flags & PT_FLAG_STRICT_SEARCH) != 0;
-#define LAUNCH(M, S) do { st = set_lds(ctx, k_probe_hits<M, S>, lds); if (st != PT_OK) return st; hipLaunchKernelGGL((k_probe_hits<M, S>), grid, block, lds, 0, a); } while (0)
-    if (moving) { if (strict) LAUNCH(true, true); else LAUNCH(true, false); }
-    else        { if (strict) LAUNCH(false, true); else LAUNCH(false, false); }
-#undef LAUNCH
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipDeviceSynchronize());
-    HIPCHK(ctx, hipMemcpy(out_t, ot.p, n * 4ull, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(out_prim, op.p, n * 4ull, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(out_point, opt.p, n * 12ull, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(out_normal, on.p, n * 12ull, hipMemcpyDeviceToHost));
-    return PT_OK;
-}
-
 int pt_hip_probe_primitives(pt_ctx* ctx, uint32_t n, const float* rays, const float* spheres, const float* planes, float* out_ts, float* out_tp)
 {
     if (!ctx || !rays || !spheres || !planes || !out_ts || !out_tp) return PT_ERR_INVALID;
@@ -616,6 +689,34 @@ int pt_hip_probe_primitives(pt_ctx* ctx, uint32_t n, const float* rays, const fl
     return PT_OK;
 }
 
+int pt_hip_probe_hits(pt_ctx* ctx, uint32_t n, const float* rays, const float* times, uint32_t flags,
+                      float* out_t, int32_t* out_prim, float* out_point, float* out_normal)
+{
+    int st = check_scene(ctx);
+    if (st != PT_OK) return st;
+    if (!rays || !times || !out_t || !out_prim || !out_point || !out_normal) return PT_ERR_INVALID;
+    if (n == 0) return PT_OK;
+    Bind b(ctx);
+    int mode; const SceneArgs* sc; size_t lds;
+    st = select_mode(ctx, flags, 4, false, &mode, &sc, &lds);
+    if (st != PT_OK) return st;
+    DevBuf dr, dt, ot, op, opt, on;
+    HIPCHK(ctx, dr.alloc(n * 24ull)); HIPCHK(ctx, dt.alloc(n * 4ull)); HIPCHK(ctx, ot.alloc(n * 4ull));
+    HIPCHK(ctx, op.alloc(n * 4ull)); HIPCHK(ctx, opt.alloc(n * 12ull)); HIPCHK(ctx, on.alloc(n * 12ull));
+    HIPCHK(ctx, hipMemcpy(dr.p, rays, n * 24ull, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(dt.p, times, n * 4ull, hipMemcpyHostToDevice));
+    ProbeHitsArgs a{*sc, n, dr.as<float>(), dt.as<float>(), ot.as<float>(), op.as<int32_t>(), opt.as<float>(), on.as<float>()};
+    const dim3 grid((n + 255) / 256), block(256);
+    PT_LAUNCH(k_probe_hits, ctx->moving, mode, grid, block, lds, 0, a);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(out_t, ot.p, n * 4ull, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out_prim, op.p, n * 4ull, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out_point, opt.p, n * 12ull, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out_normal, on.p, n * 12ull, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 int pt_hip_probe_get_rays(pt_ctx* ctx, uint32_t n, const float* uv, const float* tape, const uint64_t* ofs, float* out_rays)
 {
     int st = check_scene(ctx);
@@ -629,7 +730,7 @@ int pt_hip_probe_get_rays(pt_ctx* ctx, uint32_t n, const float* uv, const float*
     HIPCHK(ctx, hipMemcpy(duv.p, uv, n * 8ull, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(dtape.p, tape, ntape * 4ull, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(dofs.p, ofs, (n + 1ull) * 8, hipMemcpyHostToDevice));
-    ProbeRaysArgs a{ctx->sc.cam, n, duv.as<float>(), dtape.as<float>(), dofs.as<unsigned long long>(), dout.as<float>()};
+    ProbeRaysArgs a{ctx->sc_bvh.cam, n, duv.as<float>(), dtape.as<float>(), dofs.as<unsigned long long>(), dout.as<float>()};
     hipLaunchKernelGGL(k_probe_get_rays, dim3((n + 255) / 256), dim3(256), 0, 0, a);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipDeviceSynchronize());
@@ -681,8 +782,9 @@ int pt_hip_probe_paths(pt_ctx* ctx, uint32_t n, const float* rays, const float* 
     if (!rays || !times || !tape32 || !ofs32 || !tape64 || !ofs64 || !out_rgba) return PT_ERR_INVALID;
     if (n == 0) return PT_OK;
     Bind b(ctx);
-    const size_t lds = lds_bytes_probe(ctx->sc);
-    if (lds > ctx->lds_limit) return PT_ERR_UNSUPPORTED;
+    int mode; const SceneArgs* sc; size_t lds;
+    st = select_mode(ctx, flags, 4, false, &mode, &sc, &lds);
+    if (st != PT_OK) return st;
     const uint64_t n32 = ofs32[n], n64 = ofs64[n];
     DevBuf dr, dt, dt32, do32, dt64, do64, oc, os;
     HIPCHK(ctx, dr.alloc(n * 24ull)); HIPCHK(ctx, dt.alloc(n * 4ull));
@@ -694,14 +796,10 @@ int pt_hip_probe_paths(pt_ctx* ctx, uint32_t n, const float* rays, const float* 
     if (n64) HIPCHK(ctx, hipMemcpy(dt64.p, tape64, n64 * 8, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(do32.p, ofs32, (n + 1ull) * 8, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(do64.p, ofs64, (n + 1ull) * 8, hipMemcpyHostToDevice));
-    ProbePathsArgs a{ctx->sc, n, max_depth, dr.as<float>(), dt.as<float>(), dt32.as<float>(), do32.as<unsigned long long>(),
+    ProbePathsArgs a{*sc, n, max_depth, dr.as<float>(), dt.as<float>(), dt32.as<float>(), do32.as<unsigned long long>(),
                      dt64.as<double>(), do64.as<unsigned long long>(), oc.as<float>(), os.as<uint32_t>()};
     const dim3 grid((n + 255) / 256), block(256);
-    const bool moving = ctx->blob.moving, strict = (flags & PT_FLAG_STRICT_SEARCH) != 0;
-#define LAUNCH(M, S) do { st = set_lds(ctx, k_probe_paths<M, S>, lds); if (st != PT_OK) return st; hipLaunchKernelGGL((k_probe_paths<M, S>), grid, block, lds, 0, a); } while (0)
-    if (moving) { if (strict) LAUNCH(true, true); else LAUNCH(true, false); }
-    else        { if (strict) LAUNCH(false, true); else LAUNCH(false, false); }
-#undef LAUNCH
+    PT_LAUNCH(k_probe_paths, ctx->moving, mode, grid, block, lds, 0, a);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipDeviceSynchronize());
     HIPCHK(ctx, hipMemcpy(out_rgba, oc.p, n * 16ull, hipMemcpyDeviceToHost));
@@ -718,19 +816,16 @@ int pt_hip_probe_samples(pt_ctx* ctx, const pt_params* p, uint32_t n, const uint
     if (n == 0) return PT_OK;
     for (uint32_t i = 0; i < n; ++i) if (pixels[i] >= (uint64_t)p->width * p->height) return PT_ERR_INVALID;
     Bind b(ctx);
-    const size_t lds = lds_bytes_probe(ctx->sc);
-    if (lds > ctx->lds_limit) return PT_ERR_UNSUPPORTED;
+    int mode; const SceneArgs* sc; size_t lds;
+    st = select_mode(ctx, p->flags, 4, false, &mode, &sc, &lds);
+    if (st != PT_OK) return st;
     DevBuf dp, ds, oc, os;
     HIPCHK(ctx, dp.alloc(n * 4ull)); HIPCHK(ctx, ds.alloc(n * 4ull)); HIPCHK(ctx, oc.alloc(n * 16ull)); HIPCHK(ctx, os.alloc(n * 4ull));
     HIPCHK(ctx, hipMemcpy(dp.p, pixels, n * 4ull, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ds.p, samples, n * 4ull, hipMemcpyHostToDevice));
-    ProbeSamplesArgs a{ctx->sc, n, p->width, p->height, p->max_depth, p->seed, dp.as<uint32_t>(), ds.as<uint32_t>(), oc.as<float>(), os.as<uint32_t>()};
+    ProbeSamplesArgs a{*sc, n, p->width, p->height, p->max_depth, p->seed, dp.as<uint32_t>(), ds.as<uint32_t>(), oc.as<float>(), os.as<uint32_t>()};
     const dim3 grid((n + 255) / 256), block(256);
-    const bool moving = ctx->blob.moving, strict = (p->flags & PT_FLAG_STRICT_SEARCH) != 0;
-#define LAUNCH(M, S) do { st = set_lds(ctx, k_probe_samples<M, S>, lds); if (st != PT_OK) return st; hipLaunchKernelGGL((k_probe_samples<M, S>), grid, block, lds, 0, a); } while (0)
-    if (moving) { if (strict) LAUNCH(true, true); else LAUNCH(true, false); }
-    else        { if (strict) LAUNCH(false, true); else LAUNCH(false, false); }
-#undef LAUNCH
+    PT_LAUNCH(k_probe_samples, ctx->moving, mode, grid, block, lds, 0, a);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipDeviceSynchronize());
     HIPCHK(ctx, hipMemcpy(out_rgba, oc.p, n * 16ull, hipMemcpyDeviceToHost));

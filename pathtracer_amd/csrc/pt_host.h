@@ -3,6 +3,9 @@
 // order and is compiled without contraction (-ffp-contract=off; baseline x86-64 has no FMA anyway).
 #pragma once
 #include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -51,12 +54,56 @@ inline int validate_desc(const pt_scene_desc* d)
 struct Blob
 {
     std::vector<float4> f4;
-    uint32_t off_velp = 0, off_smat = 0, off_planes = 0, off_pmat = 0, npairs = 0, idx_mask = 1;
+    std::vector<uint32_t> order; // slot -> original sphere index (0xFFFFFFFF = unused slot)
+    uint32_t off_velp = 0, off_groups = 0, off_smat = 0, off_planes = 0, off_pmat = 0, npairs = 0, ngroups = 0, idx_mask = 1;
     bool moving = false;
 };
 
 inline float4 f4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 inline float bits_to_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+// Spatial order for the groups of 8: spheres of similar size first (a few huge spheres would otherwise blow up the
+// bounds of the small ones they are mixed with), Morton order of the mid-time centre inside a size class.
+inline void spatial_order(const pt_scene_desc* d, std::vector<uint32_t>* order)
+{
+    const uint32_t ns = d->n_spheres;
+    order->resize(ns);
+    if (!ns) return;
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    const float tm = 0.5f * (d->t0 + d->t1);
+    std::vector<float> mid(3 * (size_t)ns);
+    for (uint32_t i = 0; i < ns; ++i)
+        for (int k = 0; k < 3; ++k)
+        {
+            float c = d->sphere_pos_r[4 * (size_t)i + k] + (d->sphere_vel ? d->sphere_vel[3 * (size_t)i + k] * tm : 0.0f);
+            mid[3 * (size_t)i + k] = c;
+            if (c < lo[k]) lo[k] = c;
+            if (c > hi[k]) hi[k] = c;
+        }
+    std::vector<uint64_t> key(ns);
+    auto spread = [](uint64_t v) { // 21 bits -> every third bit
+        v &= 0x1FFFFF; v = (v | v << 32) & 0x1F00000000FFFFull; v = (v | v << 16) & 0x1F0000FF0000FFull;
+        v = (v | v << 8) & 0x100F00F00F00F00Full; v = (v | v << 4) & 0x10C30C30C30C30C3ull; v = (v | v << 2) & 0x1249249249249249ull;
+        return v;
+    };
+    for (uint32_t i = 0; i < ns; ++i)
+    {
+        uint64_t m = 0;
+        for (int k = 0; k < 3; ++k)
+        {
+            float ext = hi[k] - lo[k];
+            float u = ext > 0 ? (mid[3 * (size_t)i + k] - lo[k]) / ext : 0.0f;
+            uint64_t q = (uint64_t)(u * 2097151.0f);
+            m |= spread(q) << k;
+        }
+        float r = d->sphere_pos_r[4 * (size_t)i + 3];
+        int cls = 0;
+        if (r > 0) { int e; frexpf(r, &e); cls = 64 - (e / 2); } // bigger spheres first, classes a factor 4 apart
+        key[i] = ((uint64_t)(cls & 0x7F) << 57) ^ (m >> 7);
+        (*order)[i] = i;
+    }
+    std::stable_sort(order->begin(), order->end(), [&key](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+}
 
 // Layout: see ptd::SceneView.
 inline void build_blob(const pt_scene_desc* d, Blob* b)
@@ -66,20 +113,26 @@ inline void build_blob(const pt_scene_desc* d, Blob* b)
     if (d->sphere_vel)
         for (uint32_t i = 0; i < 3 * ns; ++i)
             if (d->sphere_vel[i] != 0.0f) { b->moving = true; break; }
-    b->npairs = (ns + 1) / 2;
+    b->ngroups = ((ns + 7) / 8 + 3) / 4 * 4; // whole batches of four bounds
+    b->npairs = 4 * b->ngroups;
+    const uint32_t slots = 2 * b->npairs;
     uint32_t bits = 1;
-    while ((1u << bits) < 2 * b->npairs) ++bits;
+    while ((1u << bits) < slots) ++bits;
     b->idx_mask = (1u << bits) - 1;
+    std::vector<uint32_t> sorted;
+    spatial_order(d, &sorted);
+    b->order.assign(slots, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < ns; ++i) b->order[i] = sorted[i];
     b->f4.clear();
-    // spheres, two per entry.  r2 = radius*radius as the reference forms it (geometry.cpp:47).  The odd slot of an
-    // odd-sized scene is a sphere with r2 = -1: its discriminant is negative for every ray.
+    // spheres, two per entry.  r2 = radius*radius as the reference forms it (geometry.cpp:47).  An unused slot is a
+    // sphere with r2 = -1: its discriminant is negative for every ray.
     for (uint32_t j = 0; j < b->npairs; ++j)
     {
         float cx[2] = {0, 0}, cy[2] = {0, 0}, cz[2] = {0, 0}, r2[2] = {-1.0f, -1.0f};
         for (uint32_t l = 0; l < 2; ++l)
         {
-            uint32_t i = 2 * j + l;
-            if (i >= ns) continue;
+            uint32_t i = b->order[2 * j + l];
+            if (i == 0xFFFFFFFFu) continue;
             const float* s = d->sphere_pos_r + 4 * (size_t)i;
             cx[l] = s[0]; cy[l] = s[1]; cz[l] = s[2]; r2[l] = s[3] * s[3];
         }
@@ -93,18 +146,56 @@ inline void build_blob(const pt_scene_desc* d, Blob* b)
             float vx[2] = {0, 0}, vy[2] = {0, 0}, vz[2] = {0, 0};
             for (uint32_t l = 0; l < 2; ++l)
             {
-                uint32_t i = 2 * j + l;
-                if (i >= ns) continue;
+                uint32_t i = b->order[2 * j + l];
+                if (i == 0xFFFFFFFFu) continue;
                 const float* v = d->sphere_vel + 3 * (size_t)i;
                 vx[l] = v[0]; vy[l] = v[1]; vz[l] = v[2];
             }
             b->f4.push_back(f4(vx[0], vx[1], vy[0], vy[1]));
             b->f4.push_back(f4(vz[0], vz[1], 0, 0));
         }
-    b->off_smat = (uint32_t)b->f4.size();
-    for (uint32_t i = 0; i < ns; ++i)
+    // group bounds: sphere around the box of the members' centres at t0 and t1, radius = farthest member surface, padded
+    b->off_groups = (uint32_t)b->f4.size();
     {
-        b->f4.push_back(f4(bits_to_float(d->sphere_mat_type[i]), d->sphere_mat_param[2 * i], d->sphere_mat_param[2 * i + 1], 0));
+        std::vector<float> gb(4 * (size_t)b->ngroups);
+        for (uint32_t g = 0; g < b->ngroups; ++g)
+        {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, c[3] = {0, 0, 0}, R = -1;
+            for (int pass = 0; pass < 2; ++pass)
+            {
+                if (pass == 1) { if (lo[0] > hi[0]) break; for (int k = 0; k < 3; ++k) c[k] = 0.5 * (lo[k] + hi[k]); R = 0; }
+                for (uint32_t l = 0; l < 8; ++l)
+                {
+                    uint32_t i = b->order[8 * g + l];
+                    if (i == 0xFFFFFFFFu) continue;
+                    for (int e2 = 0; e2 < 2; ++e2)
+                    {
+                        double t = e2 ? d->t1 : d->t0, p[3], dist2 = 0;
+                        for (int k = 0; k < 3; ++k)
+                        {
+                            p[k] = (double)d->sphere_pos_r[4 * (size_t)i + k] + (b->moving ? (double)d->sphere_vel[3 * (size_t)i + k] * t : 0.0);
+                            if (pass == 0) { if (p[k] < lo[k]) lo[k] = p[k]; if (p[k] > hi[k]) hi[k] = p[k]; }
+                            else dist2 += (p[k] - c[k]) * (p[k] - c[k]);
+                        }
+                        if (pass == 1) { double far = sqrt(dist2) + fabs((double)d->sphere_pos_r[4 * (size_t)i + 3]); if (far > R) R = far; }
+                    }
+                }
+            }
+            // the search is approximate arithmetic: pad, so that no sphere the exact test could hit is culled;
+            // an empty group keeps R2 = -1 (never touched)
+            double R2 = R < 0 ? -1.0 : (R * (1.0 + 1e-4) + 1e-4) * (R * (1.0 + 1e-4) + 1e-4);
+            gb[4 * (size_t)g] = (float)c[0]; gb[4 * (size_t)g + 1] = (float)c[1]; gb[4 * (size_t)g + 2] = (float)c[2]; gb[4 * (size_t)g + 3] = (float)R2;
+        }
+        for (uint32_t q = 0; q < b->ngroups / 4; ++q)
+            for (int k = 0; k < 4; ++k)
+                b->f4.push_back(f4(gb[16 * (size_t)q + k], gb[16 * (size_t)q + 4 + k], gb[16 * (size_t)q + 8 + k], gb[16 * (size_t)q + 12 + k]));
+    }
+    b->off_smat = (uint32_t)b->f4.size();
+    for (uint32_t sl = 0; sl < slots; ++sl)
+    {
+        uint32_t i = b->order[sl];
+        if (i == 0xFFFFFFFFu) { b->f4.push_back(f4(0, 0, 0, bits_to_float(0xFFFFFFFFu))); b->f4.push_back(f4(0, 0, 0, 0)); continue; }
+        b->f4.push_back(f4(bits_to_float(d->sphere_mat_type[i]), d->sphere_mat_param[2 * (size_t)i], d->sphere_mat_param[2 * (size_t)i + 1], bits_to_float(i)));
         const float* c = d->sphere_mat_rgba + 4 * (size_t)i;
         b->f4.push_back(f4(c[0], c[1], c[2], c[3]));
     }

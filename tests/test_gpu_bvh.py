@@ -1,0 +1,97 @@
+"""GPU: the BVH-in-HBM kernel family (scenes that overflow LDS, or PT_FLAG_FORCE_BVH) against the oracle.
+Leaf tests run in reference arithmetic and the query is the true closest hit, so the bar is bit-exact, whatever the tree."""
+import numpy as np
+import pytest
+
+import pathtracer_amd as pt
+from oracle import pyoracle as po
+from tests import _gen
+from tests._util import bit_equal, to_pt_scene, builtin_scene_arrays
+
+pytestmark = pytest.mark.gpu
+
+
+def big_scenes():
+    rng = np.random.default_rng(77)
+    return {
+        "scene2_2400": (builtin_scene_arrays(2, 16 / 9), 0),                   # overflows LDS -> BVH chosen automatically
+        "random5000": (builtin_scene_arrays(5, 16 / 9, 5000), 0),
+        "scene1_forced": (builtin_scene_arrays(1, 16 / 9), pt.FLAG_FORCE_BVH),
+        "scene3_moving_forced": (builtin_scene_arrays(3, 16 / 9), pt.FLAG_FORCE_BVH),
+        "random_moving_300_forced": (_gen.random_scene(rng, 300, n_planes=2, moving=True, extent=14.0), pt.FLAG_FORCE_BVH),
+        "tiny_3_forced": (_gen.random_scene(rng, 3, n_planes=1), pt.FLAG_FORCE_BVH),      # root is a leaf
+        "planes_only_forced": (_gen.random_scene(rng, 0, n_planes=2), pt.FLAG_FORCE_BVH),
+    }
+
+
+SCENES = big_scenes()
+
+
+@pytest.fixture(scope="module", params=list(SCENES))
+def scene(request, renderer, oracle):
+    sa, flags = SCENES[request.param]
+    renderer.upload(to_pt_scene(sa))
+    h = oracle.scene(sa)
+    yield request.param, sa, h, flags
+    oracle.scene_free(h)
+
+
+def _rays(oracle, sa, n, seed):
+    rng = np.random.default_rng(seed)
+    uv = rng.uniform(0, 1, size=(n, 2)).astype(np.float32)
+    cam_rays, _, _ = oracle.get_rays(sa.camera, 0, uv)
+    if sa.n_spheres == 0:
+        return cam_rays, np.full(n, sa.t0, np.float32)
+    return _gen.scene_rays(rng, sa, n, cam_rays)
+
+
+def test_bvh_hits_bit_exact(scene, renderer, oracle):
+    name, sa, h, flags = scene
+    rays, times = _rays(oracle, sa, 8192, 5)
+    t, prim, p, nr = renderer.probe_hits(rays, times, flags)
+    to, po_, pto, nro = oracle.closest_hits(h, rays, times, po.QUERY_CLOSEST)
+    assert (prim == po_).all(), (name, int((prim != po_).sum()))
+    assert bit_equal(t, to) and bit_equal(p, pto) and bit_equal(nr, nro), name
+
+
+def test_bvh_samples_bit_exact(scene, renderer, oracle):
+    name, sa, h, flags = scene
+    rng = np.random.default_rng(6)
+    w, hgt, n = 160, 90, 3000
+    pixels, samples = rng.integers(0, w * hgt, n).astype(np.uint32), rng.integers(0, 9999, n).astype(np.uint32)
+    c, segs = renderer.probe_samples(w, hgt, pixels, samples, 50, seed=8, flags=flags)
+    co, segso = oracle.samples_philox(h, w, hgt, pixels, samples, 50, seed=8)
+    assert (segs == segso).all(), name
+    assert bit_equal(c, co), name
+
+
+def test_bvh_render_equals_oracle(scene, renderer, oracle):
+    name, sa, h, flags = scene
+    w, hgt, spp, depth = 52, 30, 3, 12
+    img = renderer.render(w, hgt, 0, spp, depth, seed=4, flags=flags)
+    st = renderer.stats()
+    ref, seg = oracle.render_philox(h, w, hgt, 0, spp, depth, seed=4)
+    assert st["kernel"] == 1 and st["segments"] == seg, name
+    assert np.abs(img - ref).max() <= 8 * spp * 2.0 ** -24 * max(1.0, float(np.abs(ref).max()) / spp), name
+    if sa.n_spheres:
+        assert st["node_visits"] > 0 or sa.n_spheres <= 4
+        assert st["sphere_tests"] > 0
+
+
+def test_lds_and_bvh_paths_agree(renderer, oracle):
+    """Same scene through both kernel families: identical per-sample radiance (both implement the closest-hit definition)."""
+    sa = builtin_scene_arrays(1, 16 / 9)
+    renderer.upload(to_pt_scene(sa))
+    rng = np.random.default_rng(9)
+    w, hgt, n = 320, 180, 20000
+    pixels, samples = rng.integers(0, w * hgt, n).astype(np.uint32), rng.integers(0, 512, n).astype(np.uint32)
+    a, _ = renderer.probe_samples(w, hgt, pixels, samples, 50, seed=1, flags=pt.FLAG_STRICT_SEARCH)
+    b, _ = renderer.probe_samples(w, hgt, pixels, samples, 50, seed=1, flags=pt.FLAG_FORCE_BVH)
+    assert bit_equal(a, b)
+    with pytest.raises(pt.PtError) as e:   # contradictory flags
+        renderer.probe_samples(w, hgt, pixels[:4], samples[:4], 5, flags=pt.FLAG_FORCE_BVH | pt.FLAG_FORCE_LDS)
+    assert e.value.status == pt.PT_ERR_UNSUPPORTED
+    renderer.upload(pt.Scene.builtin(2, 16 / 9))
+    with pytest.raises(pt.PtError) as e:   # 2400 spheres do not fit in LDS
+        renderer.render(16, 9, 0, 1, 5, flags=pt.FLAG_FORCE_LDS)
+    assert e.value.status == pt.PT_ERR_UNSUPPORTED

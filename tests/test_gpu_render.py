@@ -1,4 +1,4 @@
-"""GPU render tests: the production kernel (k_render_lds through pt_hip_render / pt_hip_render_device) against the
+"""GPU render tests: the production kernel (k_render through pt_hip_render / pt_hip_render_device) against the
 oracle's Philox render, plus the size-independent properties checked at BASELINE.json's full sizes."""
 import ctypes as C
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from a tools/profile.sh run: HBM bytes per launch of k_render_lds from the PMC counters,
+"""profiles/traffic.json from a tools/profile.sh run: HBM bytes per launch of k_render from the PMC counters,
 corrected as MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE reads HALF the bytes
 of a wide coalesced read (x2); WRITE_SIZE is exact for 16-B-per-lane stores (our only stores)."""
 import csv, glob, json, os, sys

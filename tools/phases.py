@@ -16,6 +16,7 @@ for lib in ("libpt_hip_stamps.so", "libpt_hip.so"):
     tot = sum(st["phase_cycles"]) or 1
     print(lib, json.dumps({"kernel_ms": round(st["kernel_ms"], 3), "Msamples/s": round(st["samples"] / st["kernel_ms"] / 1e3, 1),
           "sbar": round(st["segments"] / st["samples"], 4), "lane_util": round(st["segments"] / (64 * st["wave_iterations"]), 4),
+          "groups_searched_frac": round(st["sphere_tests"] / 512 / max(1, st["wave_iterations"]) / max(1, -(-r.scene.n_spheres // 8)), 4),
           "iters_per_wave": round(st["wave_iterations"] / ((w // 8) * (h // 8)), 1),
           "share_refill": round(st["phase_cycles"][0] / tot, 4), "share_hit": round(st["phase_cycles"][1] / tot, 4),
           "share_shade": round(st["phase_cycles"][2] / tot, 4),

@@ -69,9 +69,17 @@ typedef struct pt_params {
     uint64_t seed;                /* Philox key */
 } pt_params;
 
-#define PT_FLAG_STRICT_SEARCH 1u /* closest-sphere search in reference arithmetic for every sphere (slow; parity tests) */
-#define PT_FLAG_FORCE_BVH 2u     /* use the HBM BVH kernel even if the scene fits in LDS */
-#define PT_FLAG_FORCE_LDS 4u     /* fail with PT_ERR_UNSUPPORTED instead of falling back to the BVH kernel */
+/* How the closest-sphere query is answered (all give the same definition of the answer):
+ *   default            : BVH traversal with the tree staged in LDS when it fits (book-1 scene: 18 KB), else from HBM
+ *   PT_FLAG_BRUTE_FORCE: two-level brute force over the LDS-resident SoA scene in packed FP32 (the FP32-VALU-bound
+ *                        formulation of BASELINE.json's north star; approximate search + exact re-evaluation)
+ *   PT_FLAG_STRICT_SEARCH: brute force in reference arithmetic for every sphere (slow; parity tests)
+ *   PT_FLAG_FORCE_BVH  : BVH traversal from HBM even if the scene fits in LDS
+ *   PT_FLAG_FORCE_LDS  : fail with PT_ERR_UNSUPPORTED rather than read the scene from HBM */
+#define PT_FLAG_STRICT_SEARCH 1u
+#define PT_FLAG_FORCE_BVH 2u
+#define PT_FLAG_FORCE_LDS 4u
+#define PT_FLAG_BRUTE_FORCE 8u
 
 typedef struct pt_stats {
     uint64_t samples;       /* width*height*(spp_end-spp_begin) */
@@ -81,7 +89,7 @@ typedef struct pt_stats {
     uint64_t wave_iterations; /* trips of the per-wave segment loop; lane utilisation = segments / (64 * wave_iterations) */
     uint64_t phase_cycles[3]; /* diagnostic builds (-DPT_STAMPS) only: shader cycles in refill / closest-hit / shading; else 0 */
     double kernel_ms;       /* HIP-event time of the render kernel on its stream */
-    uint32_t kernel;        /* 0 = LDS brute force, 1 = BVH in HBM */
+    uint32_t kernel;        /* 0 = LDS brute force (fast), 1 = BVH in HBM, 2 = LDS brute force (strict), 3 = BVH in LDS */
     uint32_t reserved;
 } pt_stats;
 

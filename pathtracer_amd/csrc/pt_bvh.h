@@ -56,8 +56,20 @@ inline void build_bvh(const pt_scene_desc* d, BvhData* out)
     if (d->sphere_vel)
         for (size_t i = 0; i < 3 * (size_t)n; ++i)
             if (d->sphere_vel[i] != 0.0f) { out->moving = true; break; }
-    // swept, padded boxes: the device's slab test is ordinary f32 arithmetic, the leaf test is the reference's exact
-    // one; the pad keeps every sphere the exact test could hit inside its box.
+    // swept, padded boxes: the device's slab test is ordinary f32 arithmetic whose rounding error in position space is
+    // a few ulp of the largest coordinate involved (ray origins lie on scene surfaces or at the camera); the leaf test
+    // is the reference's exact one.  The pad -- 16 ulp of the scene extent plus 1e-5 of the radius -- keeps every sphere
+    // the exact test could hit inside its box.
+    float extent = 1.0f;
+    for (int k = 0; k < 3; ++k) if (fabsf(d->camera[k]) > extent) extent = fabsf(d->camera[k]);
+    for (uint32_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k)
+        {
+            float a = fabsf(d->sphere_pos_r[4 * (size_t)i + k]) + fabsf(d->sphere_pos_r[4 * (size_t)i + 3]);
+            if (out->moving) a += fabsf(d->sphere_vel[3 * (size_t)i + k]) * (fabsf(d->t0) > fabsf(d->t1) ? fabsf(d->t0) : fabsf(d->t1));
+            if (a > extent) extent = a;
+        }
+    const float extentPad = extent * 1.0e-6f;
     std::vector<Aabb> box(n);
     std::vector<float> cen(3 * (size_t)n);
     for (uint32_t i = 0; i < n; ++i)
@@ -69,7 +81,7 @@ inline void build_bvh(const pt_scene_desc* d, BvhData* out)
             float a = s[k], b2 = s[k];
             if (out->moving) { float v = d->sphere_vel[3 * (size_t)i + k]; a = s[k] + v * d->t0; b2 = s[k] + v * d->t1; }
             float lo = (a < b2 ? a : b2) - r, hi = (a > b2 ? a : b2) + r;
-            float pad = 1e-4f * (fabsf(lo) > fabsf(hi) ? fabsf(lo) : fabsf(hi)) + 1e-4f * r + 1e-6f;
+            float pad = extentPad + 1e-5f * r;
             box[i].lo[k] = lo - pad; box[i].hi[k] = hi + pad;
             cen[3 * (size_t)i + k] = 0.5f * (lo + hi);
         }

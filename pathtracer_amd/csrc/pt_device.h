@@ -346,12 +346,37 @@ template <bool MOVING> PT_DEV int32_t search_spheres_strict(const SceneView& s, 
 // so the result is the exact closest hit (smallest t > kMinT, lowest original index on an exact tie) whatever the
 // tree looks like -- the same definition the LDS search implements.
 constexpr uint32_t kBvhLeafFlag = 0x80000000u;
-constexpr uint32_t kBvhStack = 32; // >= tree depth, guaranteed by the host builder (median fallback)
+constexpr uint32_t kBvhStack = 32; // stack entries per lane when the tree lives in HBM; >= tree depth + 1 (host checks)
 struct BvhView
 {
     const float4* nodes; const float4* sph; const float4* vel; const float4* mat;
     uint32_t root_ref, n_spheres;
 };
+
+PT_DEV bool sphere_clearly_missed(const Ray& ray, V3 c, float r2)
+{
+#pragma clang fp contract(fast)
+    const float ox = ray.o.x - c.x, oy = ray.o.y - c.y, oz = ray.o.z - c.z;
+    const float hb = ox * ray.d.x + oy * ray.d.y + oz * ray.d.z;
+    const float oo = ox * ox + oy * oy + oz * oz;
+    const float disc = hb * hb - (oo - r2);
+    // rounding of either evaluation is bounded by a few ulp of the terms that cancel (hb^2 and |oc|^2)
+    return disc < -1e-5f * (hb * hb + oo);
+}
+
+// Slab test of one child box against the ray segment [0, best]; contracted arithmetic (boxes are padded by the builder).
+PT_DEV bool box_hit(float lox, float loy, float loz, float hix, float hiy, float hiz, float ix, float iy, float iz,
+                    float nox, float noy, float noz, float best, float* tnear)
+{
+#pragma clang fp contract(fast)
+    const float a0 = lox * ix + nox, a1 = hix * ix + nox; // (lo - o) * inv as lo*inv - o*inv
+    const float b0 = loy * iy + noy, b1 = hiy * iy + noy;
+    const float c0 = loz * iz + noz, c1 = hiz * iz + noz;
+    const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+    const float tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+    *tnear = tn;
+    return tf >= fmaxf(tn, 0.0f) && tn <= best;
+}
 
 template <bool MOVING>
 PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float tLimit, uint32_t* stack /* this lane's column, stride 64 */,
@@ -364,10 +389,13 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
     if (b.n_spheres != 0)
     {
         // finite reciprocals: a zero direction component must not turn (lo - o) * inv into NaN
-        const float big = 1.0e30f;
-        const float ix = fabsf(ray.d.x) > 1e-30f ? 1.0f / ray.d.x : (ray.d.x < 0 ? -big : big);
-        const float iy = fabsf(ray.d.y) > 1e-30f ? 1.0f / ray.d.y : (ray.d.y < 0 ? -big : big);
-        const float iz = fabsf(ray.d.z) > 1e-30f ? 1.0f / ray.d.z : (ray.d.z < 0 ? -big : big);
+        const float big = 1.0e18f;
+        const float ix = fabsf(ray.d.x) > 1e-18f ? 1.0f / ray.d.x : (ray.d.x < 0 ? -big : big);
+        const float iy = fabsf(ray.d.y) > 1e-18f ? 1.0f / ray.d.y : (ray.d.y < 0 ? -big : big);
+        const float iz = fabsf(ray.d.z) > 1e-18f ? 1.0f / ray.d.z : (ray.d.z < 0 ? -big : big);
+        // The slab test as lo*inv + (-o*inv): one fma per plane.  Its rounding error, mapped back to position space, is a
+        // few ulp of max(|o|, |lo|) -- the builder pads every box by 16 ulp of the scene extent (camera included).
+        const float nox = -ray.o.x * ix, noy = -ray.o.y * iy, noz = -ray.o.z * iz;
         uint32_t sp = 0, cur = b.root_ref;
         for (;;)
         {
@@ -380,8 +408,11 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
                     const float4 sd = b.sph[slot];
                     V3 c = v3(sd.x, sd.y, sd.z);
                     if (MOVING) { const float4 vd = b.vel[slot]; c = add(c, mul(v3(vd.x, vd.y, vd.z), time)); } // main.cpp:66
-                    const float t = intersect_sphere_exact(ray, c, sd.w);
                     ++*sphereTests;
+                    // cheap conservative filter: most spheres of a visited leaf are missed; only a ray whose quarter
+                    // discriminant is not clearly negative gets the exact (correctly rounded sqrt / divide) evaluation
+                    if (sphere_clearly_missed(ray, c, sd.w)) continue;
+                    const float t = intersect_sphere_exact(ray, c, sd.w);
                     if (t > kMinT && t <= best)
                     {
                         const uint32_t orig = __float_as_uint(b.mat[2 * slot].w);
@@ -395,19 +426,10 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
             {
                 const float4 n0 = b.nodes[4 * cur], n1 = b.nodes[4 * cur + 1], n2 = b.nodes[4 * cur + 2], n3 = b.nodes[4 * cur + 3];
                 ++*nodeVisits;
-                // slabs of the left box {n0.xyz .. n0.w, n1.x, n1.y} and the right box {n1.z, n1.w, n2.x .. n2.yzw}
-                float a0 = (n0.x - ray.o.x) * ix, a1 = (n0.w - ray.o.x) * ix;
-                float b0 = (n0.y - ray.o.y) * iy, b1 = (n1.x - ray.o.y) * iy;
-                float c0 = (n0.z - ray.o.z) * iz, c1 = (n1.y - ray.o.z) * iz;
-                const float nearL = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
-                const float farL = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
-                a0 = (n1.z - ray.o.x) * ix; a1 = (n2.y - ray.o.x) * ix;
-                b0 = (n1.w - ray.o.y) * iy; b1 = (n2.z - ray.o.y) * iy;
-                c0 = (n2.x - ray.o.z) * iz; c1 = (n2.w - ray.o.z) * iz;
-                const float nearR = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
-                const float farR = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
-                const bool hitL = farL >= fmaxf(nearL, 0.0f) && nearL <= best;
-                const bool hitR = farR >= fmaxf(nearR, 0.0f) && nearR <= best;
+                // left box {n0.xyz .. n0.w, n1.x, n1.y}, right box {n1.z, n1.w, n2.x .. n2.yzw}
+                float nearL, nearR;
+                const bool hitL = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, best, &nearL);
+                const bool hitR = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, best, &nearR);
                 const uint32_t refL = __float_as_uint(n3.x), refR = __float_as_uint(n3.y);
                 if (hitL && hitR)
                 {
@@ -433,7 +455,7 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
 struct Hit { float t; int32_t prim; V3 point, normal; Material m; };
 
 // How the sphere query is answered.
-enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2 };
+enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2, MODE_BVH_LDS = 3 }; // BVH: tree in HBM; BVH_LDS: tree staged in LDS
 struct QueryCtx // per-lane scratch and counters of the sphere query
 {
     BvhView bvh; uint32_t* stack; uint32_t searched, nodeVisits, sphereTests;
@@ -459,7 +481,7 @@ template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, cons
     V3 centre = v3(0, 0, 0);
     Material sphereMat; sphereMat.type = MAT_NONE; sphereMat.colour = v4(0, 0, 0, 0); sphereMat.roughness = 0; sphereMat.n = 0;
     uint32_t origIndex = 0;
-    if (MODE == MODE_BVH)
+    if (MODE == MODE_BVH || MODE == MODE_BVH_LDS)
     {
         obj = bvh_closest<MOVING>(q.bvh, ray, time, h.t, q.stack, &t, &centre, &q.nodeVisits, &q.sphereTests);
         if (obj >= 0) { sphereMat = load_material(q.bvh.mat, (uint32_t)obj); origIndex = __float_as_uint(q.bvh.mat[2 * (uint32_t)obj].w); }
@@ -509,7 +531,7 @@ template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, cons
             }
         }
     }
-    if (MODE != MODE_BVH && obj >= 0) { sphereMat = load_material(s.smat, (uint32_t)obj); origIndex = original_index(s, (uint32_t)obj); }
+    if (MODE != MODE_BVH && MODE != MODE_BVH_LDS && obj >= 0) { sphereMat = load_material(s.smat, (uint32_t)obj); origIndex = original_index(s, (uint32_t)obj); }
     if (obj >= 0 && t > kMinT && t < h.t)                                // main.cpp:204-216
     {
         h.t = t; h.prim = (int32_t)origIndex;

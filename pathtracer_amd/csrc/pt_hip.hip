@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <cmath>
@@ -34,15 +35,22 @@ struct SceneArgs
     uint32_t ns, npairs, ngroups, np, idx_mask;
     float t0, t1;
     DeviceCamera cam;
-    BvhView bvh;        // MODE_BVH only: nodes / spheres / materials in HBM
+    BvhView bvh;        // MODE_BVH: nodes / spheres / materials in HBM.  MODE_BVH_LDS: only root_ref / n_spheres are used,
+    uint32_t bvh_off[4]; //   the arrays sit inside the blob at these float4 offsets (nodes, sph, vel, mat)
+    uint32_t stack_entries; // per-lane traversal stack capacity carved from LDS (BVH modes)
 };
 
 // LDS carve-up behind the blob: per wave, [64 pixels x rgba] accumulators (render kernel) and, in MODE_BVH, a
 // 32 x 64 traversal stack.
-__device__ __forceinline__ QueryCtx make_query(const SceneArgs& a, uint32_t* stackBase)
+template <int MODE> __device__ __forceinline__ QueryCtx make_query(const SceneArgs& a, const float4* smem, uint32_t* stackBase)
 {
     QueryCtx q;
-    q.bvh = a.bvh; q.stack = stackBase; q.searched = 0; q.nodeVisits = 0; q.sphereTests = 0;
+    q.bvh = a.bvh;
+    if (MODE == MODE_BVH_LDS)
+    {
+        q.bvh.nodes = smem + a.bvh_off[0]; q.bvh.sph = smem + a.bvh_off[1]; q.bvh.vel = smem + a.bvh_off[2]; q.bvh.mat = smem + a.bvh_off[3];
+    }
+    q.stack = stackBase; q.searched = 0; q.nodeVisits = 0; q.sphereTests = 0;
     return q;
 }
 
@@ -82,8 +90,8 @@ __global__ void __launch_bounds__(256) k_render(RenderArgs a)
     stage_scene(smem, a.sc);
     float* acc = reinterpret_cast<float*>(smem + a.sc.blob_f4) + wave * 256u; // [64 pixels][rgba] of this wave's tile
     acc[lane] = 0.0f; acc[lane + 64] = 0.0f; acc[lane + 128] = 0.0f; acc[lane + 192] = 0.0f;
-    uint32_t* stack = reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4 + nwaves * 64u) + wave * (kBvhStack * 64u) + lane;
-    QueryCtx qc = make_query(a.sc, stack);
+    uint32_t* stack = reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4 + nwaves * 64u) + wave * (a.sc.stack_entries * 64u) + lane;
+    QueryCtx qc = make_query<MODE>(a.sc, smem, stack);
     __syncthreads();
 
     const uint32_t slot = blockIdx.x * nwaves + wave;
@@ -187,7 +195,7 @@ __global__ void __launch_bounds__(256) k_render(RenderArgs a)
         }
     }
     // ---- statistics: segments of this wave
-    if (MODE == MODE_BVH)
+    if (MODE == MODE_BVH || MODE == MODE_BVH_LDS)
     {
         for (int o = 32; o > 0; o >>= 1) { qc.nodeVisits += __shfl_xor(qc.nodeVisits, o); qc.sphereTests += __shfl_xor(qc.sphereTests, o); }
         if (lane == 0) { atomicAdd(a.stats + 6, (unsigned long long)qc.nodeVisits); atomicAdd(a.stats + 7, (unsigned long long)qc.sphereTests); }
@@ -210,7 +218,7 @@ template <bool MOVING, int MODE> __global__ void __launch_bounds__(256) k_probe_
 {
     extern __shared__ float4 smem[];
     stage_scene(smem, a.sc);
-    QueryCtx qc = make_query(a.sc, reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4) + (threadIdx.x >> 6) * (kBvhStack * 64u) + (threadIdx.x & 63u));
+    QueryCtx qc = make_query<MODE>(a.sc, smem, reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4) + (threadIdx.x >> 6) * (a.sc.stack_entries * 64u) + (threadIdx.x & 63u));
     __syncthreads();
     const SceneView s = make_view(smem, a.sc);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,7 +280,7 @@ template <bool MOVING, int MODE> __global__ void __launch_bounds__(256) k_probe_
 {
     extern __shared__ float4 smem[];
     stage_scene(smem, a.sc);
-    QueryCtx qc = make_query(a.sc, reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4) + (threadIdx.x >> 6) * (kBvhStack * 64u) + (threadIdx.x & 63u));
+    QueryCtx qc = make_query<MODE>(a.sc, smem, reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4) + (threadIdx.x >> 6) * (a.sc.stack_entries * 64u) + (threadIdx.x & 63u));
     __syncthreads();
     const SceneView s = make_view(smem, a.sc);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,7 +298,7 @@ template <bool MOVING, int MODE> __global__ void __launch_bounds__(256) k_probe_
 {
     extern __shared__ float4 smem[];
     stage_scene(smem, a.sc);
-    QueryCtx qc = make_query(a.sc, reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4) + (threadIdx.x >> 6) * (kBvhStack * 64u) + (threadIdx.x & 63u));
+    QueryCtx qc = make_query<MODE>(a.sc, smem, reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4) + (threadIdx.x >> 6) * (a.sc.stack_entries * 64u) + (threadIdx.x & 63u));
     __syncthreads();
     const SceneView s = make_view(smem, a.sc);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,13 +343,13 @@ struct pt_ctx
 {
     int device = -1;
     std::string err;
-    bool has_scene = false, moving = false, lds_ok = false;
+    bool has_scene = false, moving = false, lds_ok = false, bvh_lds_ok = false;
     // LDS mode: the whole scene as one blob; BVH mode: planes-only blob + tree and payload in HBM
     pth::Blob blob, blob_planes;
-    float4* blob_dev = nullptr; float4* blob_planes_dev = nullptr;
+    float4* blob_dev = nullptr; float4* blob_planes_dev = nullptr; float4* blob_bvh_dev = nullptr; // brute-force image, planes only, planes + tree
     float4* nodes_dev = nullptr; float4* sph_dev = nullptr; float4* vel_dev = nullptr; float4* mat_dev = nullptr;
     uint32_t bvh_nodes = 0, bvh_depth = 0;
-    SceneArgs sc_lds{}, sc_bvh{};
+    SceneArgs sc_lds{}, sc_bvh{}, sc_bvh_lds{};
     float* accum_dev = nullptr; size_t accum_floats = 0;
     unsigned long long* stats_dev = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -370,7 +378,7 @@ struct Bind // make the context's device current for the duration of a call
 };
 
 constexpr size_t kMaxLdsBytes = 128 * 1024; // of the 160 KiB per CU
-constexpr size_t kAccBytesPerWave = 64 * 16, kStackBytesPerWave = kBvhStack * 64 * 4;
+constexpr size_t kAccBytesPerWave = 64 * 16;
 
 uint32_t pick_stride(uint32_t ntiles)
 {
@@ -401,18 +409,21 @@ int check_scene(pt_ctx* ctx)
 // waves = waves per workgroup of the kernel about to be launched; acc = it needs the per-wave tile accumulators.
 int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode, const SceneArgs** sc, size_t* lds)
 {
-    const bool wantBvh = (flags & PT_FLAG_FORCE_BVH) != 0 || !ctx->lds_ok;
-    if (wantBvh && (flags & PT_FLAG_FORCE_LDS)) return PT_ERR_UNSUPPORTED;
-    if (wantBvh)
+    const bool brute = (flags & (PT_FLAG_BRUTE_FORCE | PT_FLAG_STRICT_SEARCH)) != 0;
+    if ((flags & PT_FLAG_FORCE_BVH) && ((flags & PT_FLAG_FORCE_LDS) || brute)) return PT_ERR_UNSUPPORTED;
+    if (brute)
     {
-        *mode = MODE_BVH; *sc = &ctx->sc_bvh;
-        *lds = (size_t)ctx->sc_bvh.blob_f4 * 16 + waves * ((acc ? kAccBytesPerWave : 0) + kStackBytesPerWave);
+        if (!ctx->lds_ok) return PT_ERR_UNSUPPORTED;
+        *mode = (flags & PT_FLAG_STRICT_SEARCH) ? MODE_LDS_STRICT : MODE_LDS_FAST; *sc = &ctx->sc_lds;
     }
+    else if (ctx->bvh_lds_ok && !(flags & PT_FLAG_FORCE_BVH)) { *mode = MODE_BVH_LDS; *sc = &ctx->sc_bvh_lds; }
     else
     {
-        *mode = (flags & PT_FLAG_STRICT_SEARCH) ? MODE_LDS_STRICT : MODE_LDS_FAST; *sc = &ctx->sc_lds;
-        *lds = (size_t)ctx->sc_lds.blob_f4 * 16 + waves * (acc ? kAccBytesPerWave : 0);
+        if (flags & PT_FLAG_FORCE_LDS) return PT_ERR_UNSUPPORTED;
+        *mode = MODE_BVH; *sc = &ctx->sc_bvh;
     }
+    const size_t stack = (*mode == MODE_BVH || *mode == MODE_BVH_LDS) ? (size_t)(*sc)->stack_entries * 64 * 4 : 0;
+    *lds = (size_t)(*sc)->blob_f4 * 16 + waves * ((acc ? kAccBytesPerWave : 0) + stack);
     if (*lds > ctx->lds_limit) return PT_ERR_UNSUPPORTED;
     return PT_OK;
 }
@@ -422,8 +433,8 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
     do {                                                                                                        \
         int st_ = PT_OK;                                                                                        \
         auto go_ = [&](auto kern) { st_ = set_lds(ctx, kern, lds); if (st_ == PT_OK) hipLaunchKernelGGL(kern, grid, block, lds, stream, args); }; \
-        if (moving) { if (mode == MODE_BVH) go_(KERNEL<true, MODE_BVH>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<true, MODE_LDS_STRICT>); else go_(KERNEL<true, MODE_LDS_FAST>); } \
-        else        { if (mode == MODE_BVH) go_(KERNEL<false, MODE_BVH>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<false, MODE_LDS_STRICT>); else go_(KERNEL<false, MODE_LDS_FAST>); } \
+        if (moving) { if (mode == MODE_BVH_LDS) go_(KERNEL<true, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<true, MODE_BVH>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<true, MODE_LDS_STRICT>); else go_(KERNEL<true, MODE_LDS_FAST>); } \
+        else        { if (mode == MODE_BVH_LDS) go_(KERNEL<false, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<false, MODE_BVH>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<false, MODE_LDS_STRICT>); else go_(KERNEL<false, MODE_LDS_FAST>); } \
         if (st_ != PT_OK) return st_;                                                                           \
     } while (0)
 
@@ -438,7 +449,7 @@ struct DevBuf
 
 void free_scene(pt_ctx* c)
 {
-    float4** ptrs[] = {&c->blob_dev, &c->blob_planes_dev, &c->nodes_dev, &c->sph_dev, &c->vel_dev, &c->mat_dev};
+    float4** ptrs[] = {&c->blob_dev, &c->blob_planes_dev, &c->blob_bvh_dev, &c->nodes_dev, &c->sph_dev, &c->vel_dev, &c->mat_dev};
     for (float4** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     c->has_scene = false;
 }
@@ -567,9 +578,28 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         st = upload_f4(ctx, bv.mat.data(), bv.mat.size() * 4, &ctx->mat_dev); if (st != PT_OK) return st;
         fill_scene_args(&ctx->sc_bvh, ctx->blob_planes, ctx->blob_planes_dev, d, d->n_planes);
         ctx->sc_bvh.bvh = BvhView{ctx->nodes_dev, ctx->sph_dev, ctx->vel_dev, ctx->mat_dev, bv.root_ref, bv.n_spheres};
+        ctx->sc_bvh.stack_entries = kBvhStack;
         ctx->bvh_nodes = bv.n_nodes; ctx->bvh_depth = bv.depth;
         ctx->moving = bv.moving;
-        if (bv.depth >= kBvhStack) { ctx->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
+        if (bv.depth + 1 > kBvhStack) { ctx->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
+        // (3) the same tree staged in LDS behind the planes, when planes + tree + payload + 4 waves' stacks fit
+        const uint32_t entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1;
+        const size_t f4s = ctx->blob_planes.f4.size() + (bv.nodes.size() + bv.sph.size() + bv.vel.size() + bv.mat.size()) / 4;
+        ctx->bvh_lds_ok = f4s * 16 + kWavesPerBlock * (kAccBytesPerWave + (size_t)entries * 256) <= ctx->lds_limit;
+        if (ctx->bvh_lds_ok)
+        {
+            std::vector<float> img(ctx->blob_planes.f4.size() * 4);
+            if (!img.empty()) memcpy(img.data(), ctx->blob_planes.f4.data(), img.size() * 4);
+            uint32_t off[4];
+            const std::vector<float>* parts[4] = {&bv.nodes, &bv.sph, &bv.vel, &bv.mat};
+            for (int k = 0; k < 4; ++k) { off[k] = (uint32_t)(img.size() / 4); img.insert(img.end(), parts[k]->begin(), parts[k]->end()); }
+            st = upload_f4(ctx, img.data(), img.size() * 4, &ctx->blob_bvh_dev); if (st != PT_OK) return st;
+            ctx->sc_bvh_lds = ctx->sc_bvh;
+            ctx->sc_bvh_lds.blob = ctx->blob_bvh_dev; ctx->sc_bvh_lds.blob_f4 = (uint32_t)(img.size() / 4);
+            for (int k = 0; k < 4; ++k) ctx->sc_bvh_lds.bvh_off[k] = off[k];
+            ctx->sc_bvh_lds.bvh = BvhView{nullptr, nullptr, nullptr, nullptr, bv.root_ref, bv.n_spheres};
+            ctx->sc_bvh_lds.stack_entries = entries;
+        }
     }
     ctx->has_scene = true;
     return PT_OK;
@@ -584,10 +614,12 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     Bind b(ctx);
     hipStream_t stream = (hipStream_t)stream_;
     int mode; const SceneArgs* sc; size_t lds;
-    const bool bvh = (p->flags & PT_FLAG_FORCE_BVH) != 0 || !ctx->lds_ok;
-    const uint32_t waves = bvh ? kWavesPerBlockBvh : kWavesPerBlock;
-    st = select_mode(ctx, p->flags, waves, true, &mode, &sc, &lds);
+    st = select_mode(ctx, p->flags, kWavesPerBlock, true, &mode, &sc, &lds);
     if (st != PT_OK) return st;
+    // tree in HBM: one wave per workgroup (nothing to share but 8 KB of stack each); LDS-resident scenes: 4 waves share a copy
+    uint32_t waves = mode == MODE_BVH ? kWavesPerBlockBvh : kWavesPerBlock;
+    if (const char* e = getenv("PT_WAVES_PER_WG")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) waves = (uint32_t)v; } // tuning experiments only
+    if (waves != kWavesPerBlock) { st = select_mode(ctx, p->flags, waves, true, &mode, &sc, &lds); if (st != PT_OK) return st; }
     RenderArgs a{};
     a.sc = *sc;
     a.width = p->width; a.height = p->height;
@@ -606,7 +638,7 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     ctx->last_mode = mode;
     ctx->last = pt_stats{};
     ctx->last.samples = (uint64_t)p->width * p->height * a.nspp;
-    ctx->last.kernel = mode == MODE_BVH ? 1u : 0u;
+    ctx->last.kernel = mode == MODE_BVH ? 1u : mode == MODE_BVH_LDS ? 3u : mode == MODE_LDS_STRICT ? 2u : 0u;
     return PT_OK;
 }
 
@@ -643,7 +675,7 @@ int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out)
     ctx->last.segments = st[0];
     ctx->last.wave_iterations = st[1];
     ctx->last.phase_cycles[0] = st[2]; ctx->last.phase_cycles[1] = st[3]; ctx->last.phase_cycles[2] = st[4];
-    if (ctx->last_mode == MODE_BVH)
+    if (ctx->last_mode == MODE_BVH || ctx->last_mode == MODE_BVH_LDS)
     {
         ctx->last.node_visits = st[6];   // inner nodes fetched (two box tests each)
         ctx->last.sphere_tests = st[7];  // exact leaf tests

@@ -2,7 +2,8 @@
 
 Bars (BASELINE.json north_star / task gate 3):
   * STRICT search  : bit-exact with the oracle (QUERY_CLOSEST, PRODUCT_ITERATIVE) -- integer/index AND f32 values.
-  * FAST search    : the production kernel.  Values of the chosen hit are re-evaluated in reference arithmetic, so a
+  * DEFAULT (BVH)  : the production kernel -- tree staged in LDS, leaf tests in reference arithmetic: bit-exact as well.
+  * BRUTE_FORCE    : the packed-FP32 two-level search over the LDS-resident SoA scene.  Values of the chosen hit are re-evaluated in reference arithmetic, so a
                      record either agrees bit-for-bit or the search picked another sphere / hit-vs-miss at a float
                      knife-edge (silhouettes, seams of interpenetrating spheres).  Allowed knife-edge fraction: 1e-3
                      of rays; everything else must be bit-equal.  1e-5 relative is the north star's tolerance; bit
@@ -71,7 +72,7 @@ def test_hits_strict_bit_exact(scene, renderer, oracle):
 def test_hits_fast_bit_exact_off_knife_edges(scene, renderer, oracle):
     name, sa, h = scene
     rays, times = _rays(oracle, sa, 32768, 22)
-    t, prim, pt_, nr = renderer.probe_hits(rays, times, 0)
+    t, prim, pt_, nr = renderer.probe_hits(rays, times, pt.FLAG_BRUTE_FORCE)
     to, po_, pto, nro = oracle.closest_hits(h, rays, times, po.QUERY_CLOSEST)
     same = prim == po_
     assert 1.0 - same.mean() <= KNIFE_EDGE, (name, 1.0 - same.mean())
@@ -137,7 +138,7 @@ def test_paths_fast_bit_exact_off_knife_edges(scene, renderer, oracle):
     depth = 50
     rays, times, t32, o32, t64, o64 = _path_inputs(oracle, sa, h, 16384, depth, 32)
     # a path that takes a different branch may read past its slice; give every ray slack by sharing one long tape
-    c, segs = renderer.probe_paths(rays, times, depth, t32, o32, t64, o64, 0)
+    c, segs = renderer.probe_paths(rays, times, depth, t32, o32, t64, o64, pt.FLAG_BRUTE_FORCE)
     co, _, _, _ = oracle.cast_rays_tape(h, rays, times, depth, t32, o32, t64, o64, po.QUERY_CLOSEST, po.PRODUCT_ITERATIVE)
     same = same_rows(c, co)
     assert 1.0 - same.mean() <= 3 * KNIFE_EDGE, (name, 1.0 - same.mean())  # ~3 segments per path
@@ -162,9 +163,24 @@ def test_samples_fast_mismatch_rate(scene, renderer, oracle):
     w, hgt, n = 320, 180, 40000
     pixels = rng.integers(0, w * hgt, n).astype(np.uint32)
     samples = rng.integers(0, 1 << 20, n).astype(np.uint32)
-    c, segs = renderer.probe_samples(w, hgt, pixels, samples, 50, seed=3, flags=0)
+    c, segs = renderer.probe_samples(w, hgt, pixels, samples, 50, seed=3, flags=pt.FLAG_BRUTE_FORCE)
     co, segso = oracle.samples_philox(h, w, hgt, pixels, samples, 50, seed=3)
     same = same_rows(c, co)
     assert 1.0 - same.mean() <= 3 * KNIFE_EDGE, (name, 1.0 - same.mean())
     # and the population statistics agree tightly even including the knife-edge samples
     assert abs(float(c[:, :3].mean()) - float(co[:, :3].mean())) < 2e-3
+
+
+def test_default_mode_is_bit_exact(scene, renderer, oracle):
+    """flags = 0: BVH traversal with the tree in LDS and exact leaf tests -- no knife edges at all."""
+    name, sa, h = scene
+    rays, times = _rays(oracle, sa, 16384, 23)
+    t, prim, pt_, nr = renderer.probe_hits(rays, times, 0)
+    to, po_, pto, nro = oracle.closest_hits(h, rays, times, po.QUERY_CLOSEST)
+    assert (prim == po_).all() and bit_equal(t, to) and bit_equal(pt_, pto) and bit_equal(nr, nro), name
+    rng = np.random.default_rng(43)
+    w, hgt, n = 200, 120, 8000
+    pixels, samples = rng.integers(0, w * hgt, n).astype(np.uint32), rng.integers(0, 1 << 16, n).astype(np.uint32)
+    c, segs = renderer.probe_samples(w, hgt, pixels, samples, 50, seed=12, flags=0)
+    co, segso = oracle.samples_philox(h, w, hgt, pixels, samples, 50, seed=12)
+    assert (segs == segso).all() and bit_equal(c, co), name

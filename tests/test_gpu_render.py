@@ -40,12 +40,26 @@ def test_render_strict_equals_oracle(renderer, oracle, name, sid, w, h, spp, dep
     assert np.allclose(img[..., 3], spp, rtol=1e-6)
 
 
-def test_render_fast_close_to_oracle(renderer, oracle):
+def test_render_default_equals_oracle(renderer, oracle):
+    """flags = 0 (BVH staged in LDS, exact leaf tests): the same samples as the oracle, only the summation order differs."""
+    for sid, w, h, spp, depth in ((1, 72, 40, 6, 50), (3, 64, 36, 8, 50), (4, 48, 27, 8, 50)):
+        sa = builtin_scene_arrays(sid, w / h)
+        renderer.upload(to_pt_scene(sa))
+        oh = oracle.scene(sa)
+        img = renderer.render(w, h, 0, spp, depth, seed=6)
+        st = renderer.stats()
+        ref, seg = oracle.render_philox(oh, w, h, 0, spp, depth, seed=6)
+        oracle.scene_free(oh)
+        assert st["kernel"] == 3 and st["segments"] == seg, sid
+        assert _close_sums(img, ref, spp), sid
+
+
+def test_render_brute_force_close_to_oracle(renderer, oracle):
     w, h, spp, depth = 96, 54, 16, 50
     sa = builtin_scene_arrays(1, w / h)
     renderer.upload(to_pt_scene(sa))
     oh = oracle.scene(sa)
-    img = renderer.render(w, h, 0, spp, depth, seed=9)
+    img = renderer.render(w, h, 0, spp, depth, seed=9, flags=pt.FLAG_BRUTE_FORCE)
     st = renderer.stats()
     ref, seg = oracle.render_philox(oh, w, h, 0, spp, depth, seed=9)
     oracle.scene_free(oh)
@@ -124,6 +138,11 @@ def test_error_paths(renderer):
     with pytest.raises(pt.PtError) as e:
         renderer.upload(to_pt_scene(too_many))
     assert e.value.status == pt.PT_ERR_UNSUPPORTED
+    renderer.upload(pt.Scene.builtin(3, 1.0))
+    for flags in (pt.FLAG_FORCE_BVH | pt.FLAG_FORCE_LDS, pt.FLAG_FORCE_BVH | pt.FLAG_BRUTE_FORCE, pt.FLAG_FORCE_BVH | pt.FLAG_STRICT_SEARCH):
+        with pytest.raises(pt.PtError) as e:
+            renderer.render(8, 8, 0, 1, 5, flags=flags)
+        assert e.value.status == pt.PT_ERR_UNSUPPORTED
 
 
 def test_resolve_and_pack_on_device(renderer, oracle):

@@ -5,16 +5,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pathtracer_amd as pt
 scene_id = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 w, h, spp, depth = 1920, 1080, int(sys.argv[2]) if len(sys.argv) > 2 else 64, 50
+flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 for lib in ("libpt_hip_stamps.so", "libpt_hip.so"):
     pt._lib = None
     pt.load_library(os.path.join(os.path.dirname(pt.LIB_PATH), lib))
     r = pt.Renderer(0)
     r.upload(pt.Scene.builtin(scene_id, w / h))
-    r.render(w, h, 0, spp, depth)
-    r.render(w, h, 0, spp, depth)
+    r.render(w, h, 0, spp, depth, flags=flags)
+    r.render(w, h, 0, spp, depth, flags=flags)
     st = r.stats()
     tot = sum(st["phase_cycles"]) or 1
-    print(lib, json.dumps({"kernel_ms": round(st["kernel_ms"], 3), "Msamples/s": round(st["samples"] / st["kernel_ms"] / 1e3, 1),
+    print(lib, "flags", flags, json.dumps({"kernel": st["kernel"], "nodes/seg": round(st["node_visits"] / max(1, st["segments"]), 2), "tests/seg": round(st["sphere_tests"] / max(1, st["segments"]), 2), "kernel_ms": round(st["kernel_ms"], 3), "Msamples/s": round(st["samples"] / st["kernel_ms"] / 1e3, 1),
           "sbar": round(st["segments"] / st["samples"], 4), "lane_util": round(st["segments"] / (64 * st["wave_iterations"]), 4),
           "groups_searched_frac": round(st["sphere_tests"] / 512 / max(1, st["wave_iterations"]) / max(1, -(-r.scene.n_spheres // 8)), 4),
           "iters_per_wave": round(st["wave_iterations"] / ((w // 8) * (h // 8)), 1),

@@ -22,11 +22,16 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
 
 
-def flops_per_sample(sbar, n_spheres, n_planes, moving):
-    """Algorithmic FLOPs of the brute-force formulation, SURVEY.md 8(d):
-    ray-gen 90 + per segment (14/plane + 25|31/sphere) + 75 per hit-segment shading + 8 sky terminal."""
+def flops_per_sample(sbar, n_spheres, n_planes, moving, box_tests_per_seg=None, leaf_tests_per_seg=None):
+    """Algorithmic FLOPs per sample, SURVEY.md 8(d): ray-gen 90 + per segment (14/plane + sphere query) + 75 per
+    hit-segment shading + 8 sky terminal.  Sphere query: brute force = 25|31 per sphere of the scene; BVH kernels =
+    32 per box test + 25|31 per leaf sphere test, both taken from the kernel's own device counters."""
     f_sph = 31.0 if moving else 25.0
-    return 90.0 + sbar * (14.0 * n_planes + f_sph * n_spheres) + (sbar - 1.0) * 75.0 + 8.0
+    if box_tests_per_seg is None:
+        query = f_sph * n_spheres
+    else:
+        query = 32.0 * box_tests_per_seg + f_sph * leaf_tests_per_seg
+    return 90.0 + sbar * (14.0 * n_planes + query) + (sbar - 1.0) * 75.0 + 8.0
 
 
 def cpu_baseline(scene_id, w, h, depth, spp, threads):
@@ -129,11 +134,12 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        seg = torch.tensor([float(st["segments"]), float(st["samples"]), kernel_ms], dtype=torch.float64, device=dev)
+        seg = torch.tensor([float(st["segments"]), float(st["samples"]), kernel_ms, float(st["node_visits"]), float(st["sphere_tests"])],
+                           dtype=torch.float64, device=dev)
         dist.all_reduce(seg, op=dist.ReduceOp.SUM)
-        segs, smps, kernel_ms = float(seg[0]), float(seg[1]), float(seg[2]) / world
+        segs, smps, kernel_ms, nvis, stest = float(seg[0]), float(seg[1]), float(seg[2]) / world, float(seg[3]), float(seg[4])
     else:
-        segs, smps = float(st["segments"]), float(st["samples"])
+        segs, smps, nvis, stest = float(st["segments"]), float(st["samples"]), float(st["node_visits"]), float(st["sphere_tests"])
 
     host_img = bgra.cpu() if rank == 0 else None  # outside the timed region (PCIe)
     if rank == 0:
@@ -141,7 +147,12 @@ def main():
         value = samples_per_step * args.steps / elapsed / 1e6
         sbar = segs / smps
         moving = scene.vel is not None
-        f_sample = flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving)
+        kernel_name = {0: "k_render<brute force, scene in LDS>", 1: "k_render<BVH in HBM>", 2: "k_render<strict search>", 3: "k_render<BVH in LDS>"}[st["kernel"]]
+        is_bvh = st["kernel"] in (1, 3)
+        # an inner-node visit tests both child boxes (2 x 32 FLOP); leaf tests are per sphere
+        f_sample = flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving, 2.0 * nvis / segs, stest / segs) if is_bvh else \
+            flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving)
+        f_brute = flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving)
         # roofline of the dominant kernel (k_render), per launch on one GPU
         achieved = (w * h * S) * f_sample / (kernel_ms * 1e-3) / 1e12
         traffic = None
@@ -163,8 +174,15 @@ def main():
                        "segments_per_sample": round(sbar, 4), "kernel_ms": round(kernel_ms, 3), "lib_kernel_ms_last": round(st["kernel_ms"], 3)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "k_render", "flop_per_sample": round(f_sample, 1),
-                         "note": "FP32 vector (VALU) roofline, not MFMA: BASELINE.json north_star; algorithmic FLOPs per SURVEY.md 8(d)"},
+                         "kernel": kernel_name, "flop_per_sample": round(f_sample, 1),
+                         "box_tests_per_segment": round(2.0 * nvis / segs, 2) if is_bvh else None,
+                         "leaf_sphere_tests_per_segment": round(stest / segs, 2) if is_bvh else None,
+                         "brute_force_equivalent": {"flop_per_sample": round(f_brute, 1),
+                                                    "frac": round((w * h * S) * f_brute / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)},
+                         "note": "FP32 vector (VALU) roofline, not MFMA (BASELINE.json north_star). Algorithmic FLOPs per SURVEY.md 8(d): "
+                                 "for the BVH kernels the sphere term is 32/box test + 25|31/leaf test from device counters, so frac is the "
+                                 "share of peak spent on algorithmically necessary FP32 work; brute_force_equivalent prices the same samples/s "
+                                 "with the brute-force formula (work the BVH avoids, not work done)"},
         }
         if world == 1 and args.cpu_spp > 0:
             threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))

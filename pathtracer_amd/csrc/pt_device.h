@@ -379,14 +379,14 @@ PT_DEV bool box_hit(float lox, float loy, float loz, float hix, float hiy, float
 }
 
 template <bool MOVING>
-PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float tLimit, uint32_t* stack /* this lane's column, stride 64 */,
+PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float tLimit, bool live, uint32_t* stack /* this lane's column, stride 64 */,
                            float* tOut, V3* centreOut, uint32_t* nodeVisits, uint32_t* sphereTests)
 {
     float best = tLimit;               // a plane hit found earlier wins ties against spheres (main.cpp:204)
     int32_t bestSlot = -1;
     uint32_t bestOrig = 0xFFFFFFFFu;
     V3 bestCentre = v3(0, 0, 0);
-    if (b.n_spheres != 0)
+    if (b.n_spheres != 0 && live) // a lane without a live path holds a stale ray: it must not keep the wave in the loop
     {
         // finite reciprocals: a zero direction component must not turn (lo - o) * inv into NaN
         const float big = 1.0e18f;
@@ -483,7 +483,7 @@ template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, cons
     uint32_t origIndex = 0;
     if (MODE == MODE_BVH || MODE == MODE_BVH_LDS)
     {
-        obj = bvh_closest<MOVING>(q.bvh, ray, time, h.t, q.stack, &t, &centre, &q.nodeVisits, &q.sphereTests);
+        obj = bvh_closest<MOVING>(q.bvh, ray, time, h.t, live, q.stack, &t, &centre, &q.nodeVisits, &q.sphereTests);
         if (obj >= 0) { sphereMat = load_material(q.bvh.mat, (uint32_t)obj); origIndex = __float_as_uint(q.bvh.mat[2 * (uint32_t)obj].w); }
     }
     else if (STRICT)

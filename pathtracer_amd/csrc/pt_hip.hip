@@ -74,8 +74,10 @@ struct RenderArgs
     uint32_t width, height, tiles_x, ntiles, tile_stride;
     uint32_t spp_begin, nspp, max_depth;
     uint64_t seed;
+    uint32_t nchunks, nunits;       // work units = ntiles x nchunks; chunk c covers samples [c*nspp/nchunks, (c+1)*nspp/nchunks) of the call
     float* out_sum;                 // width*height*4
-    unsigned long long* stats;      // [0] segments
+    float* partial;                 // nchunks > 1: [nchunks][height][width][4] per-chunk sums, folded in chunk order by k_fold_chunks
+    unsigned long long* stats;      // [0] segments ... [8] low word: the unit cursor the waves pull from
 };
 
 constexpr uint32_t kWavesPerBlock = 4;     // LDS modes: four waves share one staged copy of the scene
@@ -83,33 +85,16 @@ constexpr uint32_t kWavesPerBlockBvh = 1;  // BVH mode: one wave per workgroup, 
 
 // ================================================================================================ the hot kernel
 template <bool MOVING, int MODE>
-__global__ void __launch_bounds__(256) k_render(RenderArgs a)
+__global__ void __launch_bounds__(512) k_render(RenderArgs a)
 {
     extern __shared__ float4 smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     stage_scene(smem, a.sc);
     float* acc = reinterpret_cast<float*>(smem + a.sc.blob_f4) + wave * 256u; // [64 pixels][rgba] of this wave's tile
-    acc[lane] = 0.0f; acc[lane + 64] = 0.0f; acc[lane + 128] = 0.0f; acc[lane + 192] = 0.0f;
     uint32_t* stack = reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4 + nwaves * 64u) + wave * (a.sc.stack_entries * 64u) + lane;
     QueryCtx qc = make_query<MODE>(a.sc, smem, stack);
     __syncthreads();
-
-    const uint32_t slot = blockIdx.x * nwaves + wave;
-    if (slot >= a.ntiles) return;
-    // Neighbouring tiles cost alike (sky rows are cheap, the sphere field is not): a multiplicative shuffle of the
-    // tile order mixes cheap and expensive tiles over the whole launch, so the tail is one tile, not one region.
-    const uint32_t tile = (uint32_t)(((unsigned long long)slot * a.tile_stride) % a.ntiles);
-    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const SceneView s = make_view(smem, a.sc);
-
-    const uint32_t total = 64u * a.nspp; // work items of this wave: item i = (pixel i&63 of the tile, sample i>>6)
-    uint32_t next = 0;                   // wave-uniform cursor into the pool
-    bool alive = false, retired = false;
-    // The live ray is kept as six scalars: as a struct it stays an un-promoted alloca (scratch traffic in the loop).
-    float rox = 0, roy = 0, roz = 0, rdx = 0, rdy = 0, rdz = 1;
-    V4 T = v4(1, 1, 1, 1);
-    float time = 0.0f;
-    uint32_t depth = 0, p = 0;
     PhiloxRng rng; rng.init(a.seed, 0, 0);
     uint32_t segs = 0, iters = 0;
 #ifdef PT_STAMPS
@@ -119,6 +104,33 @@ __global__ void __launch_bounds__(256) k_render(RenderArgs a)
 #else
 #define PT_STAMP(var) do { } while (0)
 #endif
+
+    // Persistent waves: the grid is sized to what the chip holds at once and every wave pulls work units -- (tile,
+    // sample chunk) pairs -- from one global cursor until it runs dry.  A workgroup's staged copy of the scene then
+    // serves many tiles, and no wave's slot idles behind a slower sibling.  Every wave reaches unit >= nunits: the
+    // cursor only grows.
+  for (;;)
+  {
+    uint32_t unit = 0;
+    if (lane == 0) unit = atomicAdd(reinterpret_cast<unsigned int*>(a.stats + 8), 1u);
+    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    if (unit >= a.nunits) break;
+    const uint32_t chunk = unit / a.ntiles, slot = unit - chunk * a.ntiles;
+    // Neighbouring tiles cost alike (sky rows are cheap, the sphere field is not): a multiplicative shuffle of the
+    // tile order mixes cheap and expensive tiles over the whole launch.
+    const uint32_t tile = (uint32_t)(((unsigned long long)slot * a.tile_stride) % a.ntiles);
+    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const uint32_t s0 = (uint32_t)((unsigned long long)chunk * a.nspp / a.nchunks), s1 = (uint32_t)((unsigned long long)(chunk + 1u) * a.nspp / a.nchunks);
+    acc[lane] = 0.0f; acc[lane + 64] = 0.0f; acc[lane + 128] = 0.0f; acc[lane + 192] = 0.0f;
+
+    const uint32_t total = 64u * (s1 - s0); // work items of this unit: item i = (pixel i&63 of the tile, sample s0 + (i>>6))
+    uint32_t next = 0;                      // wave-uniform cursor into the pool
+    bool alive = false, retired = false;
+    // The live ray is kept as six scalars: as a struct it stays an un-promoted alloca (scratch traffic in the loop).
+    float rox = 0, roy = 0, roz = 0, rdx = 0, rdy = 0, rdz = 1;
+    V4 T = v4(1, 1, 1, 1);
+    float time = 0.0f;
+    uint32_t depth = 0, p = 0;
 
     for (;;)
     {
@@ -138,7 +150,7 @@ __global__ void __launch_bounds__(256) k_render(RenderArgs a)
                     const uint32_t px = tx * 8u + (p & 7u), py = ty * 8u + (p >> 3);
                     if (px < a.width && py < a.height) // ragged edge tiles: the item is skipped
                     {
-                        rng.init(a.seed, py * a.width + px, a.spp_begin + (item >> 6));
+                        rng.init(a.seed, py * a.width + px, a.spp_begin + s0 + (item >> 6));
                         const Ray r0 = begin_sample(a.sc.cam, px, py, a.width, a.height, a.sc.t0, a.sc.t1, rng, &time);
                         rox = r0.o.x; roy = r0.o.y; roz = r0.o.z; rdx = r0.d.x; rdy = r0.d.y; rdz = r0.d.z;
                         T = v4(1, 1, 1, 1);
@@ -185,15 +197,17 @@ __global__ void __launch_bounds__(256) k_render(RenderArgs a)
 #endif
     }
 
-    // ---- one 16-byte store per pixel: the only HBM traffic of the render besides staging the scene
+    // ---- one 16-byte store per pixel and unit: the only HBM traffic of the render besides staging the scene
     {
         const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
         if (px < a.width && py < a.height)
         {
             float4 v = make_float4(acc[lane * 4u], acc[lane * 4u + 1u], acc[lane * 4u + 2u], acc[lane * 4u + 3u]);
-            reinterpret_cast<float4*>(a.out_sum)[(size_t)py * a.width + px] = v;
+            float4* dst = a.nchunks > 1u ? reinterpret_cast<float4*>(a.partial) + (size_t)chunk * a.width * a.height : reinterpret_cast<float4*>(a.out_sum);
+            dst[(size_t)py * a.width + px] = v;
         }
     }
+  } // units
     // ---- statistics: segments of this wave
     if (MODE == MODE_BVH || MODE == MODE_BVH_LDS)
     {
@@ -338,6 +352,21 @@ __global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ sum,
     }
 }
 
+// Sum of the per-chunk partial images in chunk order (a fixed order: the frame does not depend on which wave ran which unit).
+__global__ void __launch_bounds__(256) k_fold_chunks(const float4* __restrict__ partial, uint32_t nchunks, uint32_t n, float4* __restrict__ out)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        float4 v = partial[i];
+        for (uint32_t c = 1; c < nchunks; ++c)
+        {
+            const float4 w = partial[(size_t)c * n + i];
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        out[i] = v;
+    }
+}
+
 // ================================================================================================ host side
 struct pt_ctx
 {
@@ -351,6 +380,8 @@ struct pt_ctx
     uint32_t bvh_nodes = 0, bvh_depth = 0;
     SceneArgs sc_lds{}, sc_bvh{}, sc_bvh_lds{};
     float* accum_dev = nullptr; size_t accum_floats = 0;
+    float* partial_dev = nullptr; size_t partial_floats = 0; // per-chunk sums of a chunked launch (grown on demand, kept)
+    int num_cus = 0;
     unsigned long long* stats_dev = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -379,6 +410,7 @@ struct Bind // make the context's device current for the duration of a call
 
 constexpr size_t kMaxLdsBytes = 128 * 1024; // of the 160 KiB per CU
 constexpr size_t kAccBytesPerWave = 64 * 16;
+constexpr size_t kStatWords = 16; // [0..7] counters, [8] unit cursor of the persistent render kernel
 
 uint32_t pick_stride(uint32_t ntiles)
 {
@@ -437,6 +469,22 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
         else        { if (mode == MODE_BVH_LDS) go_(KERNEL<false, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<false, MODE_BVH>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<false, MODE_LDS_STRICT>); else go_(KERNEL<false, MODE_LDS_FAST>); } \
         if (st_ != PT_OK) return st_;                                                                           \
     } while (0)
+
+constexpr uint64_t kUnitsPerSlot = 96; // work units per resident wave the launch aims at (measured: 60-130 is flat, fewer leaves a tail)
+constexpr uint32_t kMinChunkSpp = 8;   // never cut a tile's samples finer than this (the drain at the end of a unit idles lanes)
+constexpr uint32_t kMaxChunks = 64;
+
+// Workgroups of k_render<moving, mode> one CU holds at this block size and LDS footprint.
+int render_occupancy(pt_ctx* ctx, bool moving, int mode, int block, size_t lds, int* out)
+{
+    int st_ = PT_OK; hipError_t e = hipSuccess;
+    auto go_ = [&](auto kern) { st_ = set_lds(ctx, kern, lds); if (st_ == PT_OK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(out, kern, block, lds); };
+    if (moving) { if (mode == MODE_BVH_LDS) go_(k_render<true, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(k_render<true, MODE_BVH>); else if (mode == MODE_LDS_STRICT) go_(k_render<true, MODE_LDS_STRICT>); else go_(k_render<true, MODE_LDS_FAST>); }
+    else        { if (mode == MODE_BVH_LDS) go_(k_render<false, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(k_render<false, MODE_BVH>); else if (mode == MODE_LDS_STRICT) go_(k_render<false, MODE_LDS_STRICT>); else go_(k_render<false, MODE_LDS_FAST>); }
+    if (st_ != PT_OK) return st_;
+    HIPCHK(ctx, e);
+    return PT_OK;
+}
 
 // device scratch that frees itself
 struct DevBuf
@@ -519,7 +567,8 @@ int pt_hip_create(int device, pt_ctx** out)
         return PT_ERR_NO_DEVICE;
     }
     c->lds_limit = kMaxLdsBytes;
-    if (hipMalloc((void**)&c->stats_dev, 8 * sizeof(unsigned long long)) != hipSuccess ||
+    c->num_cus = prop.multiProcessorCount;
+    if (hipMalloc((void**)&c->stats_dev, kStatWords * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
     {
         pt_hip_destroy(c);
@@ -535,6 +584,7 @@ void pt_hip_destroy(pt_ctx* c)
     Bind b(c);
     free_scene(c);
     if (c->accum_dev) (void)hipFree(c->accum_dev);
+    if (c->partial_dev) (void)hipFree(c->partial_dev);
     if (c->stats_dev) (void)hipFree(c->stats_dev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -618,7 +668,7 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     if (st != PT_OK) return st;
     // tree in HBM: one wave per workgroup (nothing to share but 8 KB of stack each); LDS-resident scenes: 4 waves share a copy
     uint32_t waves = mode == MODE_BVH ? kWavesPerBlockBvh : kWavesPerBlock;
-    if (const char* e = getenv("PT_WAVES_PER_WG")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) waves = (uint32_t)v; } // tuning experiments only
+    if (const char* e = getenv("PT_WAVES_PER_WG")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) waves = (uint32_t)v; } // tuning experiments only
     if (waves != kWavesPerBlock) { st = select_mode(ctx, p->flags, waves, true, &mode, &sc, &lds); if (st != PT_OK) return st; }
     RenderArgs a{};
     a.sc = *sc;
@@ -628,10 +678,53 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     a.tile_stride = pick_stride(a.ntiles);
     a.spp_begin = p->spp_begin; a.nspp = p->spp_end - p->spp_begin; a.max_depth = p->max_depth; a.seed = p->seed;
     a.out_sum = accum_dev; a.stats = ctx->stats_dev;
-    const dim3 grid((a.ntiles + waves - 1) / waves), block(64 * waves);
-    HIPCHK(ctx, hipMemsetAsync(ctx->stats_dev, 0, 8 * sizeof(unsigned long long), stream));
+    // Persistent launch: as many workgroups as the chip holds at once; waves pull (tile, sample chunk) units.
+    const dim3 block(64 * waves);
+    int wgPerCu = 0;
+    st = render_occupancy(ctx, ctx->moving, mode, (int)block.x, lds, &wgPerCu);
+    if (st != PT_OK) return st;
+    if (wgPerCu < 1) { ctx->err = "render kernel does not fit a compute unit"; return PT_ERR_UNSUPPORTED; }
+    const uint64_t slots = (uint64_t)wgPerCu * (uint64_t)ctx->num_cus * waves; // waves resident at once
+    // Units per wave slot decide the tail: the launch ends within one unit's time of the first idle wave, so aim at
+    // >= kUnitsPerSlot units per slot by cutting the sample range of a tile into chunks (each >= kMinChunkSpp samples,
+    // below which the drain at the end of a unit costs more than the tail it saves).
+    uint32_t nchunks = 1;
+    if ((uint64_t)a.ntiles < kUnitsPerSlot * slots)
+    {
+        const uint64_t want = (kUnitsPerSlot * slots + a.ntiles - 1) / a.ntiles;
+        const uint64_t most = a.nspp / kMinChunkSpp ? a.nspp / kMinChunkSpp : 1;
+        nchunks = (uint32_t)(want < most ? want : most);
+        if (nchunks > kMaxChunks) nchunks = kMaxChunks;
+    }
+    if (const char* e = getenv("PT_CHUNKS")) { int v = atoi(e); if (v >= 1 && (uint32_t)v <= a.nspp && v <= 4096) nchunks = (uint32_t)v; } // tuning experiments only
+    a.nchunks = nchunks;
+    if ((uint64_t)a.ntiles * nchunks > 0xFFFFFF00ull) return PT_ERR_INVALID;
+    a.nunits = a.ntiles * nchunks;
+    if (nchunks > 1)
+    {
+        const size_t floats = (size_t)p->width * p->height * 4 * nchunks;
+        if (floats > ctx->partial_floats)
+        {
+            if (ctx->partial_dev) { (void)hipFree(ctx->partial_dev); ctx->partial_dev = nullptr; ctx->partial_floats = 0; }
+            HIPCHK(ctx, hipMalloc((void**)&ctx->partial_dev, floats * sizeof(float)));
+            ctx->partial_floats = floats;
+        }
+        a.partial = ctx->partial_dev;
+    }
+    uint64_t wgs = ((uint64_t)a.nunits + waves - 1) / waves;
+    if (wgs > (uint64_t)wgPerCu * ctx->num_cus) wgs = (uint64_t)wgPerCu * ctx->num_cus;
+    const dim3 grid((uint32_t)wgs);
+    HIPCHK(ctx, hipMemsetAsync(ctx->stats_dev, 0, kStatWords * sizeof(unsigned long long), stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     PT_LAUNCH(k_render, ctx->moving, mode, grid, block, lds, stream, a);
+    HIPCHK(ctx, hipGetLastError());
+    if (nchunks > 1)
+    {
+        const uint32_t n = p->width * p->height;
+        uint32_t blocks = (n + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(k_fold_chunks, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(ctx->partial_dev), nchunks, n, reinterpret_cast<float4*>(accum_dev));
+    }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;

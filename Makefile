@@ -41,3 +41,10 @@ clean:
 stamps: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h $(LIBDIR)/pt_world.o
 	$(HIPCC) $(HIPFLAGS) -DPT_STAMPS -c $(CSRC)/pt_hip.hip -o $(LIBDIR)/pt_hip_stamps.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(LIBDIR)/pt_hip_stamps.o $(LIBDIR)/pt_world.o -o $(LIBDIR)/libpt_hip_stamps.so
+
+# A/B experiment builds: make variant NAME=foo DEFS="-DPT_X -DPT_Y"  ->  pathtracer_amd/lib/ab/libpt_hip_foo.so (git-ignored)
+variant: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h $(LIBDIR)/pt_world.o
+	mkdir -p $(LIBDIR)/ab
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c $(CSRC)/pt_hip.hip -o $(LIBDIR)/ab/pt_hip_$(NAME).o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(LIBDIR)/ab/pt_hip_$(NAME).o $(LIBDIR)/pt_world.o -o $(LIBDIR)/ab/libpt_hip_$(NAME).so
+	rm -f $(LIBDIR)/ab/pt_hip_$(NAME).o

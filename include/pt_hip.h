@@ -116,6 +116,10 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* params, float* accum_rgba
 
 /* Statistics of the last render on this context (synchronises with it). */
 int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out);
+/* Diagnostics (no reference counterpart): the raw device counter words of the last render, for the tuning tools under
+ * tools/.  [0] segments [1] wave iterations [2..4] phase cycles [5] groups searched [6] node visits [7] sphere tests
+ * [8] units handed out [9] wave-level inner-step trips [10] wave-level leaf-step trips [11..12] their cycles (stamps build). */
+int pt_hip_debug_counters(pt_ctx* ctx, uint64_t out16[16]);
 
 /* Replaces: `clamp(pixelColour/SAMPLES_PER_PIXEL, 0, 1)` (src/main.cpp:358) and the per-pixel part of
  * write_image_to_bmp (src/file_io.h:29-45: gamma-2 sqrt, (u8)(255*c) truncation, 0xAARRGGBB) -- on the device, so

@@ -378,10 +378,28 @@ PT_DEV bool box_hit(float lox, float loy, float loz, float hix, float hiy, float
     return tf >= fmaxf(tn, 0.0f) && tn <= best;
 }
 
-template <bool MOVING>
-PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float tLimit, bool live, uint32_t* stack /* this lane's column, stride 64 */,
-                           float* tOut, V3* centreOut, uint32_t* nodeVisits, uint32_t* sphereTests)
+struct QueryCtx // per-lane scratch and counters of the sphere query
 {
+    BvhView bvh; uint32_t* stack; uint32_t searched, nodeVisits, sphereTests, leafBatch;
+#ifdef PT_STAMPS
+    uint32_t innerIters, leafIters;              // wave-level trips through the two kinds of traversal step
+    unsigned long long cycInner, cycLeaf;        // s_memtime spent in them
+#endif
+};
+#ifdef PT_STAMPS
+#define PT_QSTAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PT_QSTAMP(var) do { } while (0)
+#endif
+
+template <bool MOVING>
+PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float tLimit, bool live, QueryCtx& q, float* tOut, V3* centreOut)
+{
+    uint32_t* const stack = q.stack;   // this lane's column, stride 64
+    const uint32_t leafBatch = q.leafBatch;
+#ifdef PT_STAMPS
+    unsigned long long qs0 = 0, qs1 = 0, qs2 = 0;
+#endif
     float best = tLimit;               // a plane hit found earlier wins ties against spheres (main.cpp:204)
     int32_t bestSlot = -1;
     uint32_t bestOrig = 0xFFFFFFFFu;
@@ -390,16 +408,62 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
     {
         // finite reciprocals: a zero direction component must not turn (lo - o) * inv into NaN
         const float big = 1.0e18f;
-        const float ix = fabsf(ray.d.x) > 1e-18f ? 1.0f / ray.d.x : (ray.d.x < 0 ? -big : big);
-        const float iy = fabsf(ray.d.y) > 1e-18f ? 1.0f / ray.d.y : (ray.d.y < 0 ? -big : big);
-        const float iz = fabsf(ray.d.z) > 1e-18f ? 1.0f / ray.d.z : (ray.d.z < 0 ? -big : big);
+        // (v_rcp_f32, 1 ulp: the same relative error on both planes of an axis, far inside the builder's padding)
+        const float ix = fabsf(ray.d.x) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.x) : (ray.d.x < 0 ? -big : big);
+        const float iy = fabsf(ray.d.y) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.y) : (ray.d.y < 0 ? -big : big);
+        const float iz = fabsf(ray.d.z) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.z) : (ray.d.z < 0 ? -big : big);
         // The slab test as lo*inv + (-o*inv): one fma per plane.  Its rounding error, mapped back to position space, is a
         // few ulp of max(|o|, |lo|) -- the builder pads every box by 16 ulp of the scene extent (camera included).
         const float nox = -ray.o.x * ix, noy = -ray.o.y * iy, noz = -ray.o.z * iz;
         uint32_t sp = 0, cur = b.root_ref;
+        bool active = true;
+        // Two kinds of step, and a wave pays for both whenever its lanes disagree.  Leaf steps are the dear ones (up to
+        // four sphere tests, the exact evaluation among them), so lanes that reach a leaf WAIT there while the others keep
+        // descending; the leaf code runs once enough lanes have gathered (or nobody is left on an inner node).
         for (;;)
         {
-            if (cur & kBvhLeafFlag)
+            // ---- inner steps
+            PT_QSTAMP(qs0);
+            for (;;)
+            {
+                const bool atInner = active && !(cur & kBvhLeafFlag);
+                const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner));
+                const uint32_t nLeaf = (uint32_t)__popcll(__ballot(active && (cur & kBvhLeafFlag)));
+                if (nInner == 0u || nLeaf >= leafBatch) break;
+#ifdef PT_STAMPS
+                ++q.innerIters;
+#endif
+                if (atInner)
+                {
+                    ++q.nodeVisits;
+                    const float4 n0 = b.nodes[4 * cur], n1 = b.nodes[4 * cur + 1], n2 = b.nodes[4 * cur + 2], n3 = b.nodes[4 * cur + 3];
+                    // left box {n0.xyz .. n0.w, n1.x, n1.y}, right box {n1.z, n1.w, n2.x .. n2.yzw}
+                    float nearL, nearR;
+                    const bool hitL = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, best, &nearL);
+                    const bool hitR = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, best, &nearR);
+                    const uint32_t refL = __float_as_uint(n3.x), refR = __float_as_uint(n3.y);
+                    if (hitL && hitR)
+                    {
+                        const bool leftFirst = nearL <= nearR;
+                        stack[(sp++) * 64u] = leftFirst ? refR : refL;
+                        cur = leftFirst ? refL : refR;
+                    }
+                    else if (hitL) cur = refL;
+                    else if (hitR) cur = refR;
+                    else if (sp == 0) active = false;
+                    else cur = stack[(--sp) * 64u];
+                }
+            }
+            PT_QSTAMP(qs1);
+#ifdef PT_STAMPS
+            q.cycInner += qs1 - qs0;
+#endif
+            if (__ballot(active) == 0ull) break;
+#ifdef PT_STAMPS
+            ++q.leafIters;
+#endif
+            // ---- leaf steps: every lane that waits at a leaf
+            if (active && (cur & kBvhLeafFlag))
             {
                 const uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 7u) + 1u;
                 for (uint32_t k = 0; k < count; ++k)
@@ -408,7 +472,7 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
                     const float4 sd = b.sph[slot];
                     V3 c = v3(sd.x, sd.y, sd.z);
                     if (MOVING) { const float4 vd = b.vel[slot]; c = add(c, mul(v3(vd.x, vd.y, vd.z), time)); } // main.cpp:66
-                    ++*sphereTests;
+                    ++q.sphereTests;
                     // cheap conservative filter: most spheres of a visited leaf are missed; only a ray whose quarter
                     // discriminant is not clearly negative gets the exact (correctly rounded sqrt / divide) evaluation
                     if (sphere_clearly_missed(ray, c, sd.w)) continue;
@@ -419,32 +483,13 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
                         if (t < best || (bestSlot >= 0 && orig < bestOrig)) { best = t; bestSlot = (int32_t)slot; bestOrig = orig; bestCentre = c; }
                     }
                 }
-                if (sp == 0) break;
-                cur = stack[(--sp) * 64u];
+                if (sp == 0) active = false;
+                else cur = stack[(--sp) * 64u];
             }
-            else
-            {
-                const float4 n0 = b.nodes[4 * cur], n1 = b.nodes[4 * cur + 1], n2 = b.nodes[4 * cur + 2], n3 = b.nodes[4 * cur + 3];
-                ++*nodeVisits;
-                // left box {n0.xyz .. n0.w, n1.x, n1.y}, right box {n1.z, n1.w, n2.x .. n2.yzw}
-                float nearL, nearR;
-                const bool hitL = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, best, &nearL);
-                const bool hitR = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, best, &nearR);
-                const uint32_t refL = __float_as_uint(n3.x), refR = __float_as_uint(n3.y);
-                if (hitL && hitR)
-                {
-                    const bool leftFirst = nearL <= nearR;
-                    stack[(sp++) * 64u] = leftFirst ? refR : refL;
-                    cur = leftFirst ? refL : refR;
-                }
-                else if (hitL) cur = refL;
-                else if (hitR) cur = refR;
-                else
-                {
-                    if (sp == 0) break;
-                    cur = stack[(--sp) * 64u];
-                }
-            }
+            PT_QSTAMP(qs2);
+#ifdef PT_STAMPS
+            q.cycLeaf += qs2 - qs1;
+#endif
         }
     }
     *tOut = best;
@@ -456,10 +501,6 @@ struct Hit { float t; int32_t prim; V3 point, normal; Material m; };
 
 // How the sphere query is answered.
 enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2, MODE_BVH_LDS = 3 }; // BVH: tree in HBM; BVH_LDS: tree staged in LDS
-struct QueryCtx // per-lane scratch and counters of the sphere query
-{
-    BvhView bvh; uint32_t* stack; uint32_t searched, nodeVisits, sphereTests;
-};
 
 // First half of cast_ray (main.cpp:180-216): planes linearly, then the sphere query; closest wins, planes win ties.
 template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, const Ray& ray, float time, bool live, QueryCtx& q)
@@ -483,7 +524,7 @@ template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, cons
     uint32_t origIndex = 0;
     if (MODE == MODE_BVH || MODE == MODE_BVH_LDS)
     {
-        obj = bvh_closest<MOVING>(q.bvh, ray, time, h.t, live, q.stack, &t, &centre, &q.nodeVisits, &q.sphereTests);
+        obj = bvh_closest<MOVING>(q.bvh, ray, time, h.t, live, q, &t, &centre);
         if (obj >= 0) { sphereMat = load_material(q.bvh.mat, (uint32_t)obj); origIndex = __float_as_uint(q.bvh.mat[2 * (uint32_t)obj].w); }
     }
     else if (STRICT)
@@ -574,28 +615,27 @@ template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray
     const bool roughMetal = h.m.type == MAT_METAL && h.m.roughness > 0.0f;
     V3 unitPoint = v3(0, 0, 0);
     if (h.m.type == MAT_DIFFUSE || roughMetal) unitPoint = random_point_in_unit_sphere(rng);
+    // Every material ends in `normalize(new direction)` (main.cpp:231, 251, 293): the branches below only pick the raw
+    // direction, the normalisation -- an exact sqrt and three exact divides -- is issued once for the whole wave.
+    V3 raw = v3(0, 0, 0);
+    bool lives = true;
     if (h.m.type == MAT_DIFFUSE)                                         // main.cpp:223-234
     {
-        V3 scatterDirection = add(normalize(unitPoint), h.normal);       // random_unit_vector, utils.h:102-108
-        if (near_zero(add(scatterDirection, h.normal))) scatterDirection = h.normal; // sic (main.cpp:226)
-        out->d = normalize(scatterDirection);
-        return true;
+        raw = add(normalize(unitPoint), h.normal);                       // random_unit_vector, utils.h:102-108
+        if (near_zero(add(raw, h.normal))) raw = h.normal;               // sic (main.cpp:226)
     }
-    if (h.m.type == MAT_METAL)                                           // main.cpp:235-259
+    else if (h.m.type == MAT_METAL)                                      // main.cpp:235-259
     {
-        V3 reflectedDir = reflect_direction(ray.d, h.normal);
+        raw = reflect_direction(ray.d, h.normal);
         if (roughMetal)
         {
-            V3 centre = add(h.point, reflectedDir);
+            V3 centre = add(h.point, raw);
             V3 randomPoint = add(mul(unitPoint, h.m.roughness), centre); // utils.h:96-100
-            reflectedDir = sub(randomPoint, h.point);
+            raw = sub(randomPoint, h.point);
         }
-        out->d = normalize(reflectedDir);
-        if (dot(reflectedDir, h.normal) > 0) return true;
-        *event = EV_ABSORB;
-        return false;
+        if (!(dot(raw, h.normal) > 0)) { *event = EV_ABSORB; lives = false; }
     }
-    if (h.m.type == MAT_DIALECTRIC)                                      // main.cpp:260-297
+    else if (h.m.type == MAT_DIALECTRIC)                                 // main.cpp:260-297
     {
         float refractRatio = 1.0f / h.m.n;
         if (dot(ray.d, h.normal) > 0.0f) refractRatio = 1.0f / refractRatio;
@@ -603,23 +643,25 @@ template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray
         float sinTheta = sqrtf(1 - cosTheta * cosTheta);
         bool internalReflection = refractRatio * sinTheta > 1.0f;
         bool shouldReflect = reflectance((double)cosTheta, (double)refractRatio) > xi;
-        V3 newRayDir;
         if (internalReflection || shouldReflect)
-            newRayDir = reflect_direction(ray.d, h.normal);
+            raw = reflect_direction(ray.d, h.normal);
         else
         {
             V3 rayPerpendicular = mul(add(ray.d, mul(h.normal, cosTheta)), refractRatio);
             float d = 1 - norm_squared(rayPerpendicular);
             float ad = d < 0 ? -d : d;
             V3 rayParallel = mul(h.normal, -sqrtf(ad));
-            newRayDir = add(rayPerpendicular, rayParallel);
+            raw = add(rayPerpendicular, rayParallel);
         }
-        out->d = normalize(newRayDir);
-        return true;
     }
-    *event = EV_NONE_MAT;
-    out->d = v3(0, 0, 0);
-    return false;
+    else
+    {
+        *event = EV_NONE_MAT;
+        out->d = v3(0, 0, 0);
+        return false;
+    }
+    out->d = normalize(raw);
+    return lives;
 }
 
 PT_DEV V4 sky(const Ray& ray)                                            // main.cpp:299-304

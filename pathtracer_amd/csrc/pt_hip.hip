@@ -38,6 +38,7 @@ struct SceneArgs
     BvhView bvh;        // MODE_BVH: nodes / spheres / materials in HBM.  MODE_BVH_LDS: only root_ref / n_spheres are used,
     uint32_t bvh_off[4]; //   the arrays sit inside the blob at these float4 offsets (nodes, sph, vel, mat)
     uint32_t stack_entries; // per-lane traversal stack capacity carved from LDS (BVH modes)
+    uint32_t leaf_batch;    // lanes that must wait at a leaf before the wave runs the leaf code (BVH modes)
 };
 
 // LDS carve-up behind the blob: per wave, [64 pixels x rgba] accumulators (render kernel) and, in MODE_BVH, a
@@ -50,7 +51,10 @@ template <int MODE> __device__ __forceinline__ QueryCtx make_query(const SceneAr
     {
         q.bvh.nodes = smem + a.bvh_off[0]; q.bvh.sph = smem + a.bvh_off[1]; q.bvh.vel = smem + a.bvh_off[2]; q.bvh.mat = smem + a.bvh_off[3];
     }
-    q.stack = stackBase; q.searched = 0; q.nodeVisits = 0; q.sphereTests = 0;
+    q.stack = stackBase; q.searched = 0; q.nodeVisits = 0; q.sphereTests = 0; q.leafBatch = a.leaf_batch;
+#ifdef PT_STAMPS
+    q.innerIters = 0; q.leafIters = 0; q.cycInner = 0; q.cycLeaf = 0;
+#endif
     return q;
 }
 
@@ -212,7 +216,8 @@ __global__ void __launch_bounds__(512) k_render(RenderArgs a)
     if (MODE == MODE_BVH || MODE == MODE_BVH_LDS)
     {
         for (int o = 32; o > 0; o >>= 1) { qc.nodeVisits += __shfl_xor(qc.nodeVisits, o); qc.sphereTests += __shfl_xor(qc.sphereTests, o); }
-        if (lane == 0) { atomicAdd(a.stats + 6, (unsigned long long)qc.nodeVisits); atomicAdd(a.stats + 7, (unsigned long long)qc.sphereTests); }
+        if (lane == 0)
+ { atomicAdd(a.stats + 6, (unsigned long long)qc.nodeVisits); atomicAdd(a.stats + 7, (unsigned long long)qc.sphereTests); }
     }
     for (int o = 32; o > 0; o >>= 1) segs += __shfl_xor(segs, o);
     if (lane == 0)
@@ -220,6 +225,10 @@ __global__ void __launch_bounds__(512) k_render(RenderArgs a)
         atomicAdd(a.stats, (unsigned long long)segs);
         atomicAdd(a.stats + 1, (unsigned long long)iters);
         atomicAdd(a.stats + 5, (unsigned long long)qc.searched);
+#ifdef PT_STAMPS
+        atomicAdd(a.stats + 9, (unsigned long long)qc.innerIters); atomicAdd(a.stats + 10, (unsigned long long)qc.leafIters);
+        atomicAdd(a.stats + 11, qc.cycInner); atomicAdd(a.stats + 12, qc.cycLeaf);
+#endif
 #ifdef PT_STAMPS
         atomicAdd(a.stats + 2, cyc_refill); atomicAdd(a.stats + 3, cyc_hit); atomicAdd(a.stats + 4, cyc_shade);
 #endif
@@ -410,6 +419,7 @@ struct Bind // make the context's device current for the duration of a call
 
 constexpr size_t kMaxLdsBytes = 128 * 1024; // of the 160 KiB per CU
 constexpr size_t kAccBytesPerWave = 64 * 16;
+constexpr uint32_t kLeafBatch = 16; // BVH traversal: lanes gathered at leaves before the leaf code runs (pt_device.h, bvh_closest)
 constexpr size_t kStatWords = 16; // [0..7] counters, [8] unit cursor of the persistent render kernel
 
 uint32_t pick_stride(uint32_t ntiles)
@@ -629,6 +639,8 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         fill_scene_args(&ctx->sc_bvh, ctx->blob_planes, ctx->blob_planes_dev, d, d->n_planes);
         ctx->sc_bvh.bvh = BvhView{ctx->nodes_dev, ctx->sph_dev, ctx->vel_dev, ctx->mat_dev, bv.root_ref, bv.n_spheres};
         ctx->sc_bvh.stack_entries = kBvhStack;
+        ctx->sc_bvh.leaf_batch = kLeafBatch;
+        if (const char* e = getenv("PT_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->sc_bvh.leaf_batch = (uint32_t)v; } // tuning experiments only
         ctx->bvh_nodes = bv.n_nodes; ctx->bvh_depth = bv.depth;
         ctx->moving = bv.moving;
         if (bv.depth + 1 > kBvhStack) { ctx->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
@@ -779,6 +791,16 @@ int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out)
         ctx->last.node_visits = st[1] * 64ull * (uint64_t)ctx->sc_lds.ngroups;   // bound tests: every lane, every group, every trip
     }
     *out = ctx->last;
+    return PT_OK;
+}
+
+int pt_hip_debug_counters(pt_ctx* ctx, uint64_t out16[16])
+{
+    if (!ctx || !out16) return PT_ERR_INVALID;
+    if (!ctx->timed) return PT_ERR_NO_SCENE;
+    Bind b(ctx);
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipMemcpy(out16, ctx->stats_dev, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

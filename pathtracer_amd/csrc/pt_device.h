@@ -346,7 +346,7 @@ template <bool MOVING> PT_DEV int32_t search_spheres_strict(const SceneView& s, 
 // so the result is the exact closest hit (smallest t > kMinT, lowest original index on an exact tie) whatever the
 // tree looks like -- the same definition the LDS search implements.
 constexpr uint32_t kBvhLeafFlag = 0x80000000u;
-constexpr uint32_t kBvhStack = 32; // stack entries per lane when the tree lives in HBM; >= tree depth + 1 (host checks)
+constexpr uint32_t kBvhStack = 64; // deepest tree the traversal accepts (the per-lane LDS stack holds depth + 1 entries; host checks)
 struct BvhView
 {
     const float4* nodes; const float4* sph; const float4* vel; const float4* mat;
@@ -402,7 +402,6 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
 #endif
     float best = tLimit;               // a plane hit found earlier wins ties against spheres (main.cpp:204)
     int32_t bestSlot = -1;
-    uint32_t bestOrig = 0xFFFFFFFFu;
     V3 bestCentre = v3(0, 0, 0);
     if (b.n_spheres != 0 && live) // a lane without a live path holds a stale ray: it must not keep the wave in the loop
     {
@@ -479,8 +478,12 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
                     const float t = intersect_sphere_exact(ray, c, sd.w);
                     if (t > kMinT && t <= best)
                     {
-                        const uint32_t orig = __float_as_uint(b.mat[2 * slot].w);
-                        if (t < best || (bestSlot >= 0 && orig < bestOrig)) { best = t; bestSlot = (int32_t)slot; bestOrig = orig; bestCentre = c; }
+                        // an exact tie between two spheres goes to the lower original index; the indices are fetched
+                        // only then (a tie with the plane hit, bestSlot < 0, leaves the plane in place)
+                        bool take = t < best;
+                        if (!take && bestSlot >= 0)
+                            take = __float_as_uint(b.mat[2 * slot].w) < __float_as_uint(b.mat[2 * (uint32_t)bestSlot].w);
+                        if (take) { best = t; bestSlot = (int32_t)slot; bestCentre = c; }
                     }
                 }
                 if (sp == 0) active = false;

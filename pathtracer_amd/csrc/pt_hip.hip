@@ -49,7 +49,8 @@ template <int MODE> __device__ __forceinline__ QueryCtx make_query(const SceneAr
     q.bvh = a.bvh;
     if (MODE == MODE_BVH_LDS)
     {
-        q.bvh.nodes = smem + a.bvh_off[0]; q.bvh.sph = smem + a.bvh_off[1]; q.bvh.vel = smem + a.bvh_off[2]; q.bvh.mat = smem + a.bvh_off[3];
+        q.bvh.nodes = smem + a.bvh_off[0]; q.bvh.sph = smem + a.bvh_off[1]; q.bvh.vel = smem + a.bvh_off[2];
+        if (a.bvh_off[3] != 0xFFFFFFFFu) q.bvh.mat = smem + a.bvh_off[3]; // else: materials stay in HBM (touched once per hit)
     }
     q.stack = stackBase; q.searched = 0; q.nodeVisits = 0; q.sphereTests = 0; q.leafBatch = a.leaf_batch;
 #ifdef PT_STAMPS
@@ -89,7 +90,7 @@ constexpr uint32_t kWavesPerBlockBvh = 1;  // BVH mode: one wave per workgroup, 
 
 // ================================================================================================ the hot kernel
 template <bool MOVING, int MODE>
-__global__ void __launch_bounds__(512) k_render(RenderArgs a)
+__device__ __forceinline__ void render_body(const RenderArgs& a)
 {
     extern __shared__ float4 smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -233,6 +234,26 @@ __global__ void __launch_bounds__(512) k_render(RenderArgs a)
         atomicAdd(a.stats + 2, cyc_refill); atomicAdd(a.stats + 3, cyc_hit); atomicAdd(a.stats + 4, cyc_shade);
 #endif
     }
+}
+
+// The kernel proper, in three register budgets.  More resident waves hide the LDS / L1 latency of the traversal's
+// dependent loads; the measured optimum (book-1 1080p, tools/ab.py) is 7 waves per SIMD (<= 72 VGPRs) for the tree in
+// LDS and 6 (<= 80) for the tree in HBM and for the brute-force search; the strict search is a test oracle and is left
+// to the compiler.
+template <bool MOVING, int MODE> __global__ void __launch_bounds__(512) k_render(RenderArgs a) { render_body<MOVING, MODE>(a); }
+template <bool MOVING, int MODE> __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) k_render_w6(RenderArgs a) { render_body<MOVING, MODE>(a); }
+template <bool MOVING, int MODE> __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 7))) k_render_w7(RenderArgs a) { render_body<MOVING, MODE>(a); }
+using RenderKernel = void (*)(RenderArgs);
+template <bool MOVING, int MODE> RenderKernel render_kernel_for()
+{
+    if constexpr (MODE == MODE_BVH_LDS) return &k_render_w7<MOVING, MODE>;
+    else if constexpr (MODE == MODE_LDS_STRICT) return &k_render<MOVING, MODE>;
+    else return &k_render_w6<MOVING, MODE>;
+}
+static RenderKernel render_kernel(bool moving, int mode)
+{
+    if (moving) { if (mode == MODE_BVH_LDS) return render_kernel_for<true, MODE_BVH_LDS>(); if (mode == MODE_BVH) return render_kernel_for<true, MODE_BVH>(); if (mode == MODE_LDS_STRICT) return render_kernel_for<true, MODE_LDS_STRICT>(); return render_kernel_for<true, MODE_LDS_FAST>(); }
+    if (mode == MODE_BVH_LDS) return render_kernel_for<false, MODE_BVH_LDS>(); if (mode == MODE_BVH) return render_kernel_for<false, MODE_BVH>(); if (mode == MODE_LDS_STRICT) return render_kernel_for<false, MODE_LDS_STRICT>(); return render_kernel_for<false, MODE_LDS_FAST>();
 }
 
 // ================================================================================================ probes
@@ -419,6 +440,7 @@ struct Bind // make the context's device current for the duration of a call
 
 constexpr size_t kMaxLdsBytes = 128 * 1024; // of the 160 KiB per CU
 constexpr size_t kAccBytesPerWave = 64 * 16;
+constexpr uint32_t kMinResidentWaves = 16; // per CU: below this the LDS-resident tree loses to the tree in HBM
 constexpr uint32_t kLeafBatch = 16; // BVH traversal: lanes gathered at leaves before the leaf code runs (pt_device.h, bvh_closest)
 constexpr size_t kStatWords = 16; // [0..7] counters, [8] unit cursor of the persistent render kernel
 
@@ -484,15 +506,13 @@ constexpr uint64_t kUnitsPerSlot = 96; // work units per resident wave the launc
 constexpr uint32_t kMinChunkSpp = 8;   // never cut a tile's samples finer than this (the drain at the end of a unit idles lanes)
 constexpr uint32_t kMaxChunks = 64;
 
-// Workgroups of k_render<moving, mode> one CU holds at this block size and LDS footprint.
+// Workgroups of the render kernel for (moving, mode) one CU holds at this block size and LDS footprint.
 int render_occupancy(pt_ctx* ctx, bool moving, int mode, int block, size_t lds, int* out)
 {
-    int st_ = PT_OK; hipError_t e = hipSuccess;
-    auto go_ = [&](auto kern) { st_ = set_lds(ctx, kern, lds); if (st_ == PT_OK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(out, kern, block, lds); };
-    if (moving) { if (mode == MODE_BVH_LDS) go_(k_render<true, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(k_render<true, MODE_BVH>); else if (mode == MODE_LDS_STRICT) go_(k_render<true, MODE_LDS_STRICT>); else go_(k_render<true, MODE_LDS_FAST>); }
-    else        { if (mode == MODE_BVH_LDS) go_(k_render<false, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(k_render<false, MODE_BVH>); else if (mode == MODE_LDS_STRICT) go_(k_render<false, MODE_LDS_STRICT>); else go_(k_render<false, MODE_LDS_FAST>); }
-    if (st_ != PT_OK) return st_;
-    HIPCHK(ctx, e);
+    const RenderKernel kern = render_kernel(moving, mode);
+    int st = set_lds(ctx, kern, lds);
+    if (st != PT_OK) return st;
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(out, kern, block, lds));
     return PT_OK;
 }
 
@@ -638,7 +658,7 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         st = upload_f4(ctx, bv.mat.data(), bv.mat.size() * 4, &ctx->mat_dev); if (st != PT_OK) return st;
         fill_scene_args(&ctx->sc_bvh, ctx->blob_planes, ctx->blob_planes_dev, d, d->n_planes);
         ctx->sc_bvh.bvh = BvhView{ctx->nodes_dev, ctx->sph_dev, ctx->vel_dev, ctx->mat_dev, bv.root_ref, bv.n_spheres};
-        ctx->sc_bvh.stack_entries = kBvhStack;
+        ctx->sc_bvh.stack_entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1;
         ctx->sc_bvh.leaf_batch = kLeafBatch;
         if (const char* e = getenv("PT_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->sc_bvh.leaf_batch = (uint32_t)v; } // tuning experiments only
         ctx->bvh_nodes = bv.n_nodes; ctx->bvh_depth = bv.depth;
@@ -646,7 +666,10 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         if (bv.depth + 1 > kBvhStack) { ctx->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
         // (3) the same tree staged in LDS behind the planes, when planes + tree + payload + 4 waves' stacks fit
         const uint32_t entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1;
-        const size_t f4s = ctx->blob_planes.f4.size() + (bv.nodes.size() + bv.sph.size() + bv.vel.size() + bv.mat.size()) / 4;
+        // Materials are read once per hit, the tree and the spheres at every step: only the latter are worth LDS, and
+        // the smaller image lets more waves share a CU.
+        const bool matInLds = getenv("PT_MAT_LDS") != nullptr; // tuning experiments only
+        const size_t f4s = ctx->blob_planes.f4.size() + (bv.nodes.size() + bv.sph.size() + bv.vel.size() + (matInLds ? bv.mat.size() : 0)) / 4;
         ctx->bvh_lds_ok = f4s * 16 + kWavesPerBlock * (kAccBytesPerWave + (size_t)entries * 256) <= ctx->lds_limit;
         if (ctx->bvh_lds_ok)
         {
@@ -654,12 +677,16 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
             if (!img.empty()) memcpy(img.data(), ctx->blob_planes.f4.data(), img.size() * 4);
             uint32_t off[4];
             const std::vector<float>* parts[4] = {&bv.nodes, &bv.sph, &bv.vel, &bv.mat};
-            for (int k = 0; k < 4; ++k) { off[k] = (uint32_t)(img.size() / 4); img.insert(img.end(), parts[k]->begin(), parts[k]->end()); }
+            for (int k = 0; k < 4; ++k)
+            {
+                if (k == 3 && !matInLds) { off[k] = 0xFFFFFFFFu; continue; }
+                off[k] = (uint32_t)(img.size() / 4); img.insert(img.end(), parts[k]->begin(), parts[k]->end());
+            }
             st = upload_f4(ctx, img.data(), img.size() * 4, &ctx->blob_bvh_dev); if (st != PT_OK) return st;
             ctx->sc_bvh_lds = ctx->sc_bvh;
             ctx->sc_bvh_lds.blob = ctx->blob_bvh_dev; ctx->sc_bvh_lds.blob_f4 = (uint32_t)(img.size() / 4);
             for (int k = 0; k < 4; ++k) ctx->sc_bvh_lds.bvh_off[k] = off[k];
-            ctx->sc_bvh_lds.bvh = BvhView{nullptr, nullptr, nullptr, nullptr, bv.root_ref, bv.n_spheres};
+            ctx->sc_bvh_lds.bvh = BvhView{nullptr, nullptr, nullptr, matInLds ? nullptr : ctx->mat_dev, bv.root_ref, bv.n_spheres};
             ctx->sc_bvh_lds.stack_entries = entries;
         }
     }
@@ -675,13 +702,32 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     if ((uint64_t)p->width * p->height > 0xFFFFFFFFull || (uint64_t)(p->spp_end - p->spp_begin) * 64ull > 0xFFFFFFFFull) return PT_ERR_INVALID;
     Bind b(ctx);
     hipStream_t stream = (hipStream_t)stream_;
-    int mode; const SceneArgs* sc; size_t lds;
-    st = select_mode(ctx, p->flags, kWavesPerBlock, true, &mode, &sc, &lds);
-    if (st != PT_OK) return st;
-    // tree in HBM: one wave per workgroup (nothing to share but 8 KB of stack each); LDS-resident scenes: 4 waves share a copy
-    uint32_t waves = mode == MODE_BVH ? kWavesPerBlockBvh : kWavesPerBlock;
-    if (const char* e = getenv("PT_WAVES_PER_WG")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) waves = (uint32_t)v; } // tuning experiments only
-    if (waves != kWavesPerBlock) { st = select_mode(ctx, p->flags, waves, true, &mode, &sc, &lds); if (st != PT_OK) return st; }
+    int mode; const SceneArgs* sc; size_t lds = 0;
+    // Workgroup shape: the waves of a workgroup share one staged copy of the scene, so bigger workgroups spend less LDS
+    // per wave; take the shape that keeps the most waves resident on a CU (ties: the smaller workgroup).  With the tree
+    // in HBM there is nothing to share and one wave per workgroup packs best.
+    uint32_t waves = 0; int wgPerCu = 0;
+    uint32_t forced = 0;
+    if (const char* e = getenv("PT_WAVES_PER_WG")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) forced = (uint32_t)v; } // tuning experiments only
+    for (uint32_t flags = p->flags;;)
+    {
+        st = select_mode(ctx, flags, 1, true, &mode, &sc, &lds);
+        if (st != PT_OK) return st;
+        const uint32_t lo = forced ? forced : (mode == MODE_BVH ? kWavesPerBlockBvh : kWavesPerBlock), hi = forced ? forced : (mode == MODE_BVH ? kWavesPerBlockBvh : 8u);
+        waves = 0; wgPerCu = 0;
+        for (uint32_t wv = lo; wv <= hi; wv *= 2)
+        {
+            int m2; const SceneArgs* sc2; size_t lds2; int occ = 0;
+            if (select_mode(ctx, flags, wv, true, &m2, &sc2, &lds2) != PT_OK) continue;
+            st = render_occupancy(ctx, ctx->moving, m2, (int)(64 * wv), lds2, &occ);
+            if (st != PT_OK) return st;
+            if ((uint32_t)occ * wv > (uint32_t)wgPerCu * waves) { waves = wv; wgPerCu = occ; lds = lds2; }
+        }
+        // A tree that fits LDS only by crowding out the waves is better left in HBM (L1/L2-resident at that size).
+        if (mode == MODE_BVH_LDS && (uint32_t)wgPerCu * waves < kMinResidentWaves && !(p->flags & PT_FLAG_FORCE_LDS) && flags == p->flags) { flags |= PT_FLAG_FORCE_BVH; continue; }
+        break;
+    }
+    if (waves == 0) { ctx->err = "render kernel does not fit a compute unit"; return PT_ERR_UNSUPPORTED; }
     RenderArgs a{};
     a.sc = *sc;
     a.width = p->width; a.height = p->height;
@@ -692,10 +738,6 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     a.out_sum = accum_dev; a.stats = ctx->stats_dev;
     // Persistent launch: as many workgroups as the chip holds at once; waves pull (tile, sample chunk) units.
     const dim3 block(64 * waves);
-    int wgPerCu = 0;
-    st = render_occupancy(ctx, ctx->moving, mode, (int)block.x, lds, &wgPerCu);
-    if (st != PT_OK) return st;
-    if (wgPerCu < 1) { ctx->err = "render kernel does not fit a compute unit"; return PT_ERR_UNSUPPORTED; }
     const uint64_t slots = (uint64_t)wgPerCu * (uint64_t)ctx->num_cus * waves; // waves resident at once
     // Units per wave slot decide the tail: the launch ends within one unit's time of the first idle wave, so aim at
     // >= kUnitsPerSlot units per slot by cutting the sample range of a tile into chunks (each >= kMinChunkSpp samples,
@@ -726,9 +768,16 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     uint64_t wgs = ((uint64_t)a.nunits + waves - 1) / waves;
     if (wgs > (uint64_t)wgPerCu * ctx->num_cus) wgs = (uint64_t)wgPerCu * ctx->num_cus;
     const dim3 grid((uint32_t)wgs);
+    if (getenv("PT_VERBOSE"))
+        fprintf(stderr, "pt_hip: render mode %d, %u waves/WG, LDS %zu B/WG, %d WG/CU, grid %u, %u tiles x %u chunks\n", mode, waves, lds, wgPerCu, grid.x, a.ntiles, nchunks);
     HIPCHK(ctx, hipMemsetAsync(ctx->stats_dev, 0, kStatWords * sizeof(unsigned long long), stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
-    PT_LAUNCH(k_render, ctx->moving, mode, grid, block, lds, stream, a);
+    {
+        const RenderKernel kern = render_kernel(ctx->moving, mode);
+        st = set_lds(ctx, kern, lds);
+        if (st != PT_OK) return st;
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+    }
     HIPCHK(ctx, hipGetLastError());
     if (nchunks > 1)
     {

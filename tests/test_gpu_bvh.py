@@ -96,9 +96,16 @@ def test_lds_and_bvh_paths_agree(renderer, oracle):
         renderer.probe_samples(w, hgt, pixels[:4], samples[:4], 5, flags=pt.FLAG_FORCE_BVH | pt.FLAG_FORCE_LDS)
     assert e.value.status == pt.PT_ERR_UNSUPPORTED
     renderer.upload(pt.Scene.builtin(2, 16 / 9))
-    for flags in (pt.FLAG_FORCE_LDS, pt.FLAG_BRUTE_FORCE, pt.FLAG_STRICT_SEARCH):   # 2400 spheres do not fit in LDS
+    for flags in (pt.FLAG_BRUTE_FORCE, pt.FLAG_STRICT_SEARCH):                      # 2400 spheres: no brute-force image in LDS
         with pytest.raises(pt.PtError) as e:
             renderer.render(16, 9, 0, 1, 5, flags=flags)
         assert e.value.status == pt.PT_ERR_UNSUPPORTED
-    renderer.render(16, 9, 0, 1, 5)
-    assert renderer.stats()["kernel"] == 1                                         # tree read from HBM
+    img = renderer.render(48, 27, 0, 2, 12, seed=3)
+    assert renderer.stats()["kernel"] == 1          # the tree would fit LDS only by crowding out the waves: read from HBM
+    forced = renderer.render(48, 27, 0, 2, 12, seed=3, flags=pt.FLAG_FORCE_LDS)
+    assert renderer.stats()["kernel"] == 3          # ... but can be forced there (materials stay in HBM), same samples
+    assert np.abs(img - forced).max() <= 8 * 2 * 2.0 ** -24
+    renderer.upload(pt.Scene.builtin(5, 16 / 9, 20000))
+    with pytest.raises(pt.PtError) as e:                                            # 20000 spheres: no tree in LDS either
+        renderer.render(16, 9, 0, 1, 5, flags=pt.FLAG_FORCE_LDS)
+    assert e.value.status == pt.PT_ERR_UNSUPPORTED

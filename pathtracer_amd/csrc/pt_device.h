@@ -100,6 +100,9 @@ struct PhiloxRng
     // draw counts, and without this each of the 3 draws of a rejection attempt refills for SOME lane (three Philox
     // evaluations per attempt instead of 3/4).  Part of the stream's definition (DESIGN.md "RNG"); the oracle does the same.
     PT_DEV void align() { k = (k + 3u) & ~3u; }
+    // align() + forget the rest of the block: the next draw refills anyway, and the four words stop being live state
+    // (registers) across whatever comes in between -- the whole sphere query, in the render loop.
+    PT_DEV void park() { align(); b0 = b1 = b2 = b3 = 0; }
     PT_DEV bool overrun() const { return false; }
 };
 
@@ -111,6 +114,7 @@ struct TapeRng
     PT_DEV float f32() { if (i32 >= n32) { over = true; ++i32; return 0.5f; } return t32[i32++]; }
     PT_DEV double f64() { if (i64 >= n64) { over = true; ++i64; return 0.5; } return t64[i64++]; }
     PT_DEV void align() {}
+    PT_DEV void park() {}
     PT_DEV bool overrun() const { return over; }
 };
 
@@ -346,6 +350,7 @@ template <bool MOVING> PT_DEV int32_t search_spheres_strict(const SceneView& s, 
 // so the result is the exact closest hit (smallest t > kMinT, lowest original index on an exact tie) whatever the
 // tree looks like -- the same definition the LDS search implements.
 constexpr uint32_t kBvhLeafFlag = 0x80000000u;
+constexpr uint32_t kBvhDone = 0xFFFFFFFFu;   // stack sentinel: "nothing left" (a real leaf reference has first < 2^28, so it is never all ones)
 constexpr uint32_t kBvhStack = 64; // deepest tree the traversal accepts (the per-lane LDS stack holds depth + 1 entries; host checks)
 struct BvhView
 {
@@ -402,79 +407,84 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
 #endif
     float best = tLimit;               // a plane hit found earlier wins ties against spheres (main.cpp:204)
     int32_t bestSlot = -1;
-    V3 bestCentre = v3(0, 0, 0);
-    if (b.n_spheres != 0 && live) // a lane without a live path holds a stale ray: it must not keep the wave in the loop
+    // finite reciprocals: a zero direction component must not turn (lo - o) * inv into NaN
+    const float big = 1.0e18f;
+    // (v_rcp_f32, 1 ulp: the same relative error on both planes of an axis, far inside the builder's padding)
+    const float ix = fabsf(ray.d.x) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.x) : (ray.d.x < 0 ? -big : big);
+    const float iy = fabsf(ray.d.y) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.y) : (ray.d.y < 0 ? -big : big);
+    const float iz = fabsf(ray.d.z) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.z) : (ray.d.z < 0 ? -big : big);
+    // The slab test as lo*inv + (-o*inv): one fma per plane.  Its rounding error, mapped back to position space, is a
+    // few ulp of max(|o|, |lo|) -- the builder pads every box by 16 ulp of the scene extent (camera included).
+    const float nox = -ray.o.x * ix, noy = -ray.o.y * iy, noz = -ray.o.z * iz;
+    // The stack pointer is the LDS address itself (this lane's column, 64 dwords per level); level 0 holds a sentinel,
+    // so "pop" needs no emptiness test: popping the sentinel ends the lane's traversal.
+    uint32_t* sp = stack;
+    *sp = kBvhDone;
+    // A lane without a live path holds a stale ray: it starts on the sentinel, so it cannot keep the wave in the loop.
+    // All lanes run the loops below together (their exits are wave-uniform), which keeps the two tallies in scalar registers.
+    uint32_t cur = (live && b.n_spheres != 0) ? b.root_ref : kBvhDone;
+    // Two kinds of step, and a wave pays for both whenever its lanes disagree.  Leaf steps are the dear ones (up to
+    // four sphere tests, the exact evaluation among them), so lanes that reach a leaf WAIT there while the others keep
+    // descending; the leaf code runs once enough lanes have gathered (or nobody is left on an inner node).
+    for (;;)
     {
-        // finite reciprocals: a zero direction component must not turn (lo - o) * inv into NaN
-        const float big = 1.0e18f;
-        // (v_rcp_f32, 1 ulp: the same relative error on both planes of an axis, far inside the builder's padding)
-        const float ix = fabsf(ray.d.x) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.x) : (ray.d.x < 0 ? -big : big);
-        const float iy = fabsf(ray.d.y) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.y) : (ray.d.y < 0 ? -big : big);
-        const float iz = fabsf(ray.d.z) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.z) : (ray.d.z < 0 ? -big : big);
-        // The slab test as lo*inv + (-o*inv): one fma per plane.  Its rounding error, mapped back to position space, is a
-        // few ulp of max(|o|, |lo|) -- the builder pads every box by 16 ulp of the scene extent (camera included).
-        const float nox = -ray.o.x * ix, noy = -ray.o.y * iy, noz = -ray.o.z * iz;
-        uint32_t sp = 0, cur = b.root_ref;
-        bool active = true;
-        // Two kinds of step, and a wave pays for both whenever its lanes disagree.  Leaf steps are the dear ones (up to
-        // four sphere tests, the exact evaluation among them), so lanes that reach a leaf WAIT there while the others keep
-        // descending; the leaf code runs once enough lanes have gathered (or nobody is left on an inner node).
+        // ---- inner steps
+        PT_QSTAMP(qs0);
         for (;;)
         {
-            // ---- inner steps
-            PT_QSTAMP(qs0);
-            for (;;)
-            {
-                const bool atInner = active && !(cur & kBvhLeafFlag);
-                const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner));
-                const uint32_t nLeaf = (uint32_t)__popcll(__ballot(active && (cur & kBvhLeafFlag)));
-                if (nInner == 0u || nLeaf >= leafBatch) break;
+            const bool atInner = !(cur & kBvhLeafFlag);                  // (the sentinel carries the leaf flag)
+            const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner));
+            const uint32_t nLeaf = (uint32_t)__popcll(__ballot(!atInner && cur != kBvhDone));
+            if (nInner == 0u || nLeaf >= leafBatch) break;
 #ifdef PT_STAMPS
-                ++q.innerIters;
+            ++q.innerIters;
 #endif
-                if (atInner)
+            q.nodeVisits += nInner;                                      // wave-level tally
+            if (atInner)
+            {
+                const float4 n0 = b.nodes[4 * cur], n1 = b.nodes[4 * cur + 1], n2 = b.nodes[4 * cur + 2], n3 = b.nodes[4 * cur + 3];
+                // left box {n0.xyz .. n0.w, n1.x, n1.y}, right box {n1.z, n1.w, n2.x .. n2.yzw}
+                float nearL, nearR;
+                const bool hitL = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, best, &nearL);
+                const bool hitR = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, best, &nearR);
+                const uint32_t refL = __float_as_uint(n3.x), refR = __float_as_uint(n3.y);
+                if (hitL && hitR)
                 {
-                    ++q.nodeVisits;
-                    const float4 n0 = b.nodes[4 * cur], n1 = b.nodes[4 * cur + 1], n2 = b.nodes[4 * cur + 2], n3 = b.nodes[4 * cur + 3];
-                    // left box {n0.xyz .. n0.w, n1.x, n1.y}, right box {n1.z, n1.w, n2.x .. n2.yzw}
-                    float nearL, nearR;
-                    const bool hitL = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, best, &nearL);
-                    const bool hitR = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, best, &nearR);
-                    const uint32_t refL = __float_as_uint(n3.x), refR = __float_as_uint(n3.y);
-                    if (hitL && hitR)
-                    {
-                        const bool leftFirst = nearL <= nearR;
-                        stack[(sp++) * 64u] = leftFirst ? refR : refL;
-                        cur = leftFirst ? refL : refR;
-                    }
-                    else if (hitL) cur = refL;
-                    else if (hitR) cur = refR;
-                    else if (sp == 0) active = false;
-                    else cur = stack[(--sp) * 64u];
+                    const bool leftFirst = nearL <= nearR;
+                    sp += 64; *sp = leftFirst ? refR : refL;
+                    cur = leftFirst ? refL : refR;
                 }
+                else if (hitL) cur = refL;
+                else if (hitR) cur = refR;
+                else { cur = *sp; if (cur != kBvhDone) sp -= 64; }
             }
-            PT_QSTAMP(qs1);
+        }
+        PT_QSTAMP(qs1);
 #ifdef PT_STAMPS
-            q.cycInner += qs1 - qs0;
+        q.cycInner += qs1 - qs0;
 #endif
-            if (__ballot(active) == 0ull) break;
+        if (__ballot(cur != kBvhDone) == 0ull) break;
 #ifdef PT_STAMPS
-            ++q.leafIters;
+        ++q.leafIters;
 #endif
-            // ---- leaf steps: every lane that waits at a leaf
-            if (active && (cur & kBvhLeafFlag))
+        // ---- leaf steps: every lane that waits at a leaf
+        const bool atLeaf = (cur & kBvhLeafFlag) && cur != kBvhDone;
+        const uint32_t first = cur & 0x0FFFFFFFu, count = atLeaf ? ((cur >> 28) & 7u) + 1u : 0u;
+        for (uint32_t k = 0;; ++k)
+        {
+            const unsigned long long todo = __ballot(k < count);
+            if (todo == 0ull) break;
+            q.sphereTests += (uint32_t)__popcll(todo);                   // wave-level tally
+            if (k < count)
             {
-                const uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 7u) + 1u;
-                for (uint32_t k = 0; k < count; ++k)
+                const uint32_t slot = first + k;
+                const float4 sd = b.sph[slot];
+                V3 c = v3(sd.x, sd.y, sd.z);
+                if (MOVING) { const float4 vd = b.vel[slot]; c = add(c, mul(v3(vd.x, vd.y, vd.z), time)); } // main.cpp:66
+                // cheap conservative filter: most spheres of a visited leaf are missed; only a ray whose quarter
+                // discriminant is not clearly negative gets the exact (correctly rounded sqrt / divide) evaluation
+                if (!sphere_clearly_missed(ray, c, sd.w))
                 {
-                    const uint32_t slot = first + k;
-                    const float4 sd = b.sph[slot];
-                    V3 c = v3(sd.x, sd.y, sd.z);
-                    if (MOVING) { const float4 vd = b.vel[slot]; c = add(c, mul(v3(vd.x, vd.y, vd.z), time)); } // main.cpp:66
-                    ++q.sphereTests;
-                    // cheap conservative filter: most spheres of a visited leaf are missed; only a ray whose quarter
-                    // discriminant is not clearly negative gets the exact (correctly rounded sqrt / divide) evaluation
-                    if (sphere_clearly_missed(ray, c, sd.w)) continue;
                     const float t = intersect_sphere_exact(ray, c, sd.w);
                     if (t > kMinT && t <= best)
                     {
@@ -483,20 +493,26 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
                         bool take = t < best;
                         if (!take && bestSlot >= 0)
                             take = __float_as_uint(b.mat[2 * slot].w) < __float_as_uint(b.mat[2 * (uint32_t)bestSlot].w);
-                        if (take) { best = t; bestSlot = (int32_t)slot; bestCentre = c; }
+                        if (take) { best = t; bestSlot = (int32_t)slot; }
                     }
                 }
-                if (sp == 0) active = false;
-                else cur = stack[(--sp) * 64u];
             }
-            PT_QSTAMP(qs2);
-#ifdef PT_STAMPS
-            q.cycLeaf += qs2 - qs1;
-#endif
         }
+        if (atLeaf) { cur = *sp; if (cur != kBvhDone) sp -= 64; }
+        PT_QSTAMP(qs2);
+#ifdef PT_STAMPS
+        q.cycLeaf += qs2 - qs1;
+#endif
     }
     *tOut = best;
-    *centreOut = bestCentre;
+    V3 centre = v3(0, 0, 0);
+    if (bestSlot >= 0)                 // the winner's centre, as the leaf test saw it
+    {
+        const float4 sd = b.sph[(uint32_t)bestSlot];
+        centre = v3(sd.x, sd.y, sd.z);
+        if (MOVING) { const float4 vd = b.vel[(uint32_t)bestSlot]; centre = add(centre, mul(v3(vd.x, vd.y, vd.z), time)); }
+    }
+    *centreOut = centre;
     return bestSlot;
 }
 

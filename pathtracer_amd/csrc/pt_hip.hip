@@ -185,6 +185,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
             ++segs;
             V4 terminal;
             const bool goes_on = shade_step(ray, h, T, rng, &terminal);
+            rng.park(); // the next scatter aligns to a fresh block anyway: drop the buffered words from the live state
             rox = ray.o.x; roy = ray.o.y; roz = ray.o.z; rdx = ray.d.x; rdy = ray.d.y; rdz = ray.d.z;
             bool ended = !goes_on;
             if (goes_on && --depth == 0) { terminal = v4(0, 0, 0, 1); ended = true; } // main.cpp:175-176
@@ -216,8 +217,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     // ---- statistics: segments of this wave
     if (MODE == MODE_BVH || MODE == MODE_BVH_LDS)
     {
-        for (int o = 32; o > 0; o >>= 1) { qc.nodeVisits += __shfl_xor(qc.nodeVisits, o); qc.sphereTests += __shfl_xor(qc.sphereTests, o); }
-        if (lane == 0)
+        if (lane == 0) // both tallies are wave-level already
  { atomicAdd(a.stats + 6, (unsigned long long)qc.nodeVisits); atomicAdd(a.stats + 7, (unsigned long long)qc.sphereTests); }
     }
     for (int o = 32; o > 0; o >>= 1) segs += __shfl_xor(segs, o);
@@ -241,8 +241,13 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
 // LDS and 6 (<= 80) for the tree in HBM and for the brute-force search; the strict search is a test oracle and is left
 // to the compiler.
 template <bool MOVING, int MODE> __global__ void __launch_bounds__(512) k_render(RenderArgs a) { render_body<MOVING, MODE>(a); }
-template <bool MOVING, int MODE> __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) k_render_w6(RenderArgs a) { render_body<MOVING, MODE>(a); }
-template <bool MOVING, int MODE> __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 7))) k_render_w7(RenderArgs a) { render_body<MOVING, MODE>(a); }
+#ifdef PT_NO_EU
+#define PT_EU(n)
+#else
+#define PT_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
+template <bool MOVING, int MODE> __global__ void __launch_bounds__(512) PT_EU(6) k_render_w6(RenderArgs a) { render_body<MOVING, MODE>(a); }
+template <bool MOVING, int MODE> __global__ void __launch_bounds__(512) PT_EU(7) k_render_w7(RenderArgs a) { render_body<MOVING, MODE>(a); }
 using RenderKernel = void (*)(RenderArgs);
 template <bool MOVING, int MODE> RenderKernel render_kernel_for()
 {
@@ -658,14 +663,14 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         st = upload_f4(ctx, bv.mat.data(), bv.mat.size() * 4, &ctx->mat_dev); if (st != PT_OK) return st;
         fill_scene_args(&ctx->sc_bvh, ctx->blob_planes, ctx->blob_planes_dev, d, d->n_planes);
         ctx->sc_bvh.bvh = BvhView{ctx->nodes_dev, ctx->sph_dev, ctx->vel_dev, ctx->mat_dev, bv.root_ref, bv.n_spheres};
-        ctx->sc_bvh.stack_entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1;
+        ctx->sc_bvh.stack_entries = bv.depth + 2 < 4 ? 4 : bv.depth + 2; // sentinel + one entry per level
         ctx->sc_bvh.leaf_batch = kLeafBatch;
         if (const char* e = getenv("PT_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->sc_bvh.leaf_batch = (uint32_t)v; } // tuning experiments only
         ctx->bvh_nodes = bv.n_nodes; ctx->bvh_depth = bv.depth;
         ctx->moving = bv.moving;
-        if (bv.depth + 1 > kBvhStack) { ctx->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
+        if (bv.depth + 2 > kBvhStack) { ctx->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
         // (3) the same tree staged in LDS behind the planes, when planes + tree + payload + 4 waves' stacks fit
-        const uint32_t entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1;
+        const uint32_t entries = ctx->sc_bvh.stack_entries;
         // Materials are read once per hit, the tree and the spheres at every step: only the latter are worth LDS, and
         // the smaller image lets more waves share a CU.
         const bool matInLds = getenv("PT_MAT_LDS") != nullptr; // tuning experiments only

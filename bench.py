@@ -171,7 +171,7 @@ def main():
             "config": {"workload": f"init_test_scene_{args.scene} (book-1 final, {scene.n_spheres} spheres + {scene.n_planes} plane) "
                                    f"{w}x{h}, depth {depth}, {S} spp per GPU = {S * world} spp total",
                        "global_samples_per_step": samples_per_step, "parallelism": f"spp-split x{world} + RCCL all-reduce(sum) of the f32 accumulation buffer",
-                       "segments_per_sample": round(sbar, 4), "kernel_ms": round(kernel_ms, 3), "lib_kernel_ms_last": round(st["kernel_ms"], 3)},
+                       "segments_per_sample": round(sbar, 4), "lane_utilisation": round(st["segments"] / (64.0 * max(1, st["wave_iterations"])), 4), "kernel_ms": round(kernel_ms, 3), "lib_kernel_ms_last": round(st["kernel_ms"], 3)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                          "kernel": kernel_name, "flop_per_sample": round(f_sample, 1),

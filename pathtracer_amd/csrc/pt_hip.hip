@@ -79,11 +79,25 @@ struct RenderArgs
     uint32_t width, height, tiles_x, ntiles, tile_stride;
     uint32_t spp_begin, nspp, max_depth;
     uint64_t seed;
-    uint32_t nchunks, nunits;       // work units = ntiles x nchunks; chunk c covers samples [c*nspp/nchunks, (c+1)*nspp/nchunks) of the call
+    uint32_t nchunks, nunits;       // work units = ntiles x nchunks; chunk c covers the samples chunk_range() gives it
+    uint32_t chunk_ratio_q16, chunk_min; // the guided schedule's two parameters (chunk_size)
     float* out_sum;                 // width*height*4
     float* partial;                 // nchunks > 1: [nchunks][height][width][4] per-chunk sums, folded in chunk order by k_fold_chunks
     unsigned long long* stats;      // [0] segments ... [8] low word: the unit cursor the waves pull from
 };
+
+// Guided schedule of the sample chunks: big chunks first, small ones last.  Every unit ends with a drain (lanes idle
+// while the unit's last paths finish), so few units are wanted; the launch's tail is as long as its last units, so
+// small ones are wanted at the end.  A chunk takes the share `ratio` of the samples still to do (at most half, at least
+// `minSpp`; a remainder below 2 x minSpp goes in one piece).  Host and device run the same recurrence.
+__host__ __device__ inline uint32_t chunk_size(uint32_t remaining, uint32_t ratio_q16, uint32_t minSpp)
+{
+    if (remaining < 2u * minSpp) return remaining;
+    uint32_t u = (uint32_t)(((unsigned long long)remaining * ratio_q16) >> 16);
+    if (u > remaining / 2u) u = remaining / 2u;
+    if (u < minSpp) u = minSpp;
+    return u;
+}
 
 constexpr uint32_t kWavesPerBlock = 4;     // LDS modes: four waves share one staged copy of the scene
 constexpr uint32_t kWavesPerBlockBvh = 1;  // BVH mode: one wave per workgroup, so that LDS (8 KB of stack per wave) packs tightly
@@ -125,7 +139,13 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     // tile order mixes cheap and expensive tiles over the whole launch.
     const uint32_t tile = (uint32_t)(((unsigned long long)slot * a.tile_stride) % a.ntiles);
     const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const uint32_t s0 = (uint32_t)((unsigned long long)chunk * a.nspp / a.nchunks), s1 = (uint32_t)((unsigned long long)(chunk + 1u) * a.nspp / a.nchunks);
+    uint32_t s0 = 0, s1 = 0; // samples [s0, s1) of the call: walk the schedule up to this chunk (scalar work, once per unit)
+    for (uint32_t c = 0;; ++c)
+    {
+        s1 = s0 + chunk_size(a.nspp - s0, a.chunk_ratio_q16, a.chunk_min);
+        if (c == chunk) break;
+        s0 = s1;
+    }
     acc[lane] = 0.0f; acc[lane + 64] = 0.0f; acc[lane + 128] = 0.0f; acc[lane + 192] = 0.0f;
 
     const uint32_t total = 64u * (s1 - s0); // work items of this unit: item i = (pixel i&63 of the tile, sample s0 + (i>>6))
@@ -507,9 +527,10 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
         if (st_ != PT_OK) return st_;                                                                           \
     } while (0)
 
-constexpr uint64_t kUnitsPerSlot = 96; // work units per resident wave the launch aims at (measured: 60-130 is flat, fewer leaves a tail)
+constexpr uint64_t kGuide = 48;        // guided schedule: a unit is at most 1/kGuide of a resident wave's even share of what is left (tile cost varies ~10x: measured optimum 32-64)
 constexpr uint32_t kMinChunkSpp = 8;   // never cut a tile's samples finer than this (the drain at the end of a unit idles lanes)
-constexpr uint32_t kMaxChunks = 64;
+constexpr uint32_t kMaxChunks = 4096;  // (the walk in the kernel is linear in the chunk index)
+constexpr uint64_t kMaxPartialBytes = 4ull << 30; // per-chunk partial images the context may hold
 
 // Workgroups of the render kernel for (moving, mode) one CU holds at this block size and LDS footprint.
 int render_occupancy(pt_ctx* ctx, bool moving, int mode, int block, size_t lds, int* out)
@@ -744,18 +765,24 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     // Persistent launch: as many workgroups as the chip holds at once; waves pull (tile, sample chunk) units.
     const dim3 block(64 * waves);
     const uint64_t slots = (uint64_t)wgPerCu * (uint64_t)ctx->num_cus * waves; // waves resident at once
-    // Units per wave slot decide the tail: the launch ends within one unit's time of the first idle wave, so aim at
-    // >= kUnitsPerSlot units per slot by cutting the sample range of a tile into chunks (each >= kMinChunkSpp samples,
-    // below which the drain at the end of a unit costs more than the tail it saves).
-    uint32_t nchunks = 1;
-    if ((uint64_t)a.ntiles < kUnitsPerSlot * slots)
+    // The guided schedule (chunk_size above): a unit of the current chunk should be no more than 1/kGuide of an even
+    // share of the remaining work per resident wave -- ratio = ntiles / (kGuide x slots), capped at 1/2 per chunk.
+    uint32_t minSpp = kMinChunkSpp;
+    uint64_t guide = kGuide;
+    if (const char* e = getenv("PT_CHUNK_MIN")) { int v = atoi(e); if (v >= 1) minSpp = (uint32_t)v; }  // tuning experiments only
+    if (const char* e = getenv("PT_GUIDE")) { int v = atoi(e); if (v >= 1) guide = (uint64_t)v; }        // tuning experiments only
+    uint64_t ratio = ((uint64_t)a.ntiles << 16) / (guide * slots);
+    if (ratio > 0x8000u) ratio = 0x8000u;
+    if (getenv("PT_UNIFORM_CHUNKS")) ratio = 0;                                                          // tuning experiments only
+    uint32_t nchunks = 0;
+    for (;;)
     {
-        const uint64_t want = (kUnitsPerSlot * slots + a.ntiles - 1) / a.ntiles;
-        const uint64_t most = a.nspp / kMinChunkSpp ? a.nspp / kMinChunkSpp : 1;
-        nchunks = (uint32_t)(want < most ? want : most);
-        if (nchunks > kMaxChunks) nchunks = kMaxChunks;
+        nchunks = 0;
+        for (uint32_t s0 = 0; s0 < a.nspp; ++nchunks) s0 += chunk_size(a.nspp - s0, (uint32_t)ratio, minSpp);
+        if (nchunks <= kMaxChunks && (uint64_t)nchunks * p->width * p->height * 16ull <= kMaxPartialBytes) break;
+        minSpp *= 2; // (tiny images with huge sample counts) coarser chunks: fewer partial images
     }
-    if (const char* e = getenv("PT_CHUNKS")) { int v = atoi(e); if (v >= 1 && (uint32_t)v <= a.nspp && v <= 4096) nchunks = (uint32_t)v; } // tuning experiments only
+    a.chunk_ratio_q16 = (uint32_t)ratio; a.chunk_min = minSpp;
     a.nchunks = nchunks;
     if ((uint64_t)a.ntiles * nchunks > 0xFFFFFF00ull) return PT_ERR_INVALID;
     a.nunits = a.ntiles * nchunks;

@@ -31,10 +31,9 @@ struct SceneArgs
 {
     const float4* blob; // HBM copy of the LDS image
     uint32_t blob_f4;   // its length in float4
-    uint32_t off_velp, off_groups, off_smat, off_planes, off_pmat;
+    uint32_t off_velp, off_groups, off_smat, off_planes, off_pmat, off_cam; // off_cam: the folded DeviceCamera (4 float4)
     uint32_t ns, npairs, ngroups, np, idx_mask;
     float t0, t1;
-    DeviceCamera cam;
     BvhView bvh;        // MODE_BVH: nodes / spheres / materials in HBM.  MODE_BVH_LDS: only root_ref / n_spheres are used,
     uint32_t bvh_off[4]; //   the arrays sit inside the blob at these float4 offsets (nodes, sph, vel, mat)
     uint32_t stack_entries; // per-lane traversal stack capacity carved from LDS (BVH modes)
@@ -176,7 +175,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
                     if (px < a.width && py < a.height) // ragged edge tiles: the item is skipped
                     {
                         rng.init(a.seed, py * a.width + px, a.spp_begin + s0 + (item >> 6));
-                        const Ray r0 = begin_sample(a.sc.cam, px, py, a.width, a.height, a.sc.t0, a.sc.t1, rng, &time);
+                        const Ray r0 = begin_sample(*reinterpret_cast<const DeviceCamera*>(smem + a.sc.off_cam), px, py, a.width, a.height, a.sc.t0, a.sc.t1, rng, &time);
                         rox = r0.o.x; roy = r0.o.y; roz = r0.o.z; rdx = r0.d.x; rdy = r0.d.y; rdz = r0.d.z;
                         T = v4(1, 1, 1, 1);
                         depth = a.max_depth;
@@ -375,7 +374,7 @@ template <bool MOVING, int MODE> __global__ void __launch_bounds__(256) k_probe_
     const uint32_t pixel = a.pixels[i];
     PhiloxRng rng; rng.init(a.seed, pixel, a.samples[i]);
     float time;
-    Ray r = begin_sample(a.sc.cam, pixel % a.width, pixel / a.width, a.width, a.height, a.sc.t0, a.sc.t1, rng, &time);
+    Ray r = begin_sample(*reinterpret_cast<const DeviceCamera*>(smem + a.sc.off_cam), pixel % a.width, pixel / a.width, a.width, a.height, a.sc.t0, a.sc.t1, rng, &time);
     uint32_t n = 0;
     V4 c = cast_ray<MOVING, MODE>(s, qc, r, a.max_depth, time, rng, &n);
     a.rgba[4*i] = c.x; a.rgba[4*i+1] = c.y; a.rgba[4*i+2] = c.z; a.rgba[4*i+3] = c.w;
@@ -430,6 +429,7 @@ struct pt_ctx
     bool has_scene = false, moving = false, lds_ok = false, bvh_lds_ok = false;
     // LDS mode: the whole scene as one blob; BVH mode: planes-only blob + tree and payload in HBM
     pth::Blob blob, blob_planes;
+    DeviceCamera cam{};          // folded camera of the uploaded scene (probe_get_rays; the kernels read the copy in the scene image)
     float4* blob_dev = nullptr; float4* blob_planes_dev = nullptr; float4* blob_bvh_dev = nullptr; // brute-force image, planes only, planes + tree
     float4* nodes_dev = nullptr; float4* sph_dev = nullptr; float4* vel_dev = nullptr; float4* mat_dev = nullptr;
     uint32_t bvh_nodes = 0, bvh_depth = 0;
@@ -568,10 +568,9 @@ int upload_f4(pt_ctx* ctx, const void* host, size_t bytes, float4** dev)
 void fill_scene_args(SceneArgs* sc, const pth::Blob& b, const float4* dev, const pt_scene_desc* d, uint32_t np)
 {
     sc->blob = dev; sc->blob_f4 = (uint32_t)b.f4.size();
-    sc->off_velp = b.off_velp; sc->off_groups = b.off_groups; sc->off_smat = b.off_smat; sc->off_planes = b.off_planes; sc->off_pmat = b.off_pmat;
+    sc->off_velp = b.off_velp; sc->off_groups = b.off_groups; sc->off_smat = b.off_smat; sc->off_planes = b.off_planes; sc->off_pmat = b.off_pmat; sc->off_cam = b.off_cam;
     sc->ns = 2 * b.npairs; sc->npairs = b.npairs; sc->ngroups = b.ngroups; sc->np = np; sc->idx_mask = b.idx_mask;
     sc->t0 = d->t0; sc->t1 = d->t1;
-    pth::make_device_camera(d->camera, &sc->cam);
 }
 
 } // namespace
@@ -654,6 +653,7 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
     if (st != PT_OK) return st;
     Bind b(ctx);
     free_scene(ctx);
+    pth::make_device_camera(d->camera, &ctx->cam);
     // (1) LDS image of the whole scene, if it can fit beside the accumulators of a 4-wave workgroup
     const size_t roughBytes = (size_t)d->n_spheres * (16 + 16 + 32 + 2) + (size_t)d->n_planes * 48 + 4096;
     ctx->lds_ok = false;
@@ -958,7 +958,7 @@ int pt_hip_probe_get_rays(pt_ctx* ctx, uint32_t n, const float* uv, const float*
     HIPCHK(ctx, hipMemcpy(duv.p, uv, n * 8ull, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(dtape.p, tape, ntape * 4ull, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(dofs.p, ofs, (n + 1ull) * 8, hipMemcpyHostToDevice));
-    ProbeRaysArgs a{ctx->sc_bvh.cam, n, duv.as<float>(), dtape.as<float>(), dofs.as<unsigned long long>(), dout.as<float>()};
+    ProbeRaysArgs a{ctx->cam, n, duv.as<float>(), dtape.as<float>(), dofs.as<unsigned long long>(), dout.as<float>()};
     hipLaunchKernelGGL(k_probe_get_rays, dim3((n + 255) / 256), dim3(256), 0, 0, a);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipDeviceSynchronize());

@@ -55,7 +55,7 @@ struct Blob
 {
     std::vector<float4> f4;
     std::vector<uint32_t> order; // slot -> original sphere index (0xFFFFFFFF = unused slot)
-    uint32_t off_velp = 0, off_groups = 0, off_smat = 0, off_planes = 0, off_pmat = 0, npairs = 0, ngroups = 0, idx_mask = 1;
+    uint32_t off_velp = 0, off_groups = 0, off_smat = 0, off_planes = 0, off_pmat = 0, off_cam = 0, npairs = 0, ngroups = 0, idx_mask = 1;
     bool moving = false;
 };
 
@@ -212,6 +212,14 @@ inline void build_blob(const pt_scene_desc* d, Blob* b)
         const float* c = d->plane_mat_rgba + 4 * (size_t)i;
         b->f4.push_back(f4(c[0], c[1], c[2], c[3]));
     }
+    // the folded camera (16 floats) rides in the same image: the kernels read it from LDS where they generate rays,
+    // instead of holding it in 16 scalar registers for the whole launch
+    b->off_cam = (uint32_t)b->f4.size();
+    ptd::DeviceCamera cam;
+    make_device_camera(d->camera, &cam);
+    static_assert(sizeof(ptd::DeviceCamera) == 64, "camera = 4 float4");
+    const float* cf = reinterpret_cast<const float*>(&cam);
+    for (int k = 0; k < 4; ++k) b->f4.push_back(f4(cf[4 * k], cf[4 * k + 1], cf[4 * k + 2], cf[4 * k + 3]));
 }
 
 } // namespace pth

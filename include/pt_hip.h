@@ -116,6 +116,12 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* params, float* accum_rgba
 
 /* Statistics of the last render on this context (synchronises with it). */
 int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out);
+/* Host-only helper (no reference counterpart; touches no device): the sample-chunk schedule pt_hip_render_device uses
+ * for `nspp` samples per pixel when a tile should hand out about `ratio_q16 / 65536` of the remaining samples per chunk
+ * and never fewer than `min_spp`.  Writes up to `cap` chunk sizes to out_sizes and returns the number of chunks; the
+ * sizes sum to nspp.  Exposed so that the schedule the kernels walk can be checked without a GPU. */
+uint32_t pt_chunk_schedule(uint32_t nspp, uint32_t ratio_q16, uint32_t min_spp, uint32_t* out_sizes, uint32_t cap);
+
 /* Diagnostics (no reference counterpart): the raw device counter words of the last render, for the tuning tools under
  * tools/.  [0] segments [1] wave iterations [2..4] phase cycles [5] groups searched [6] node visits [7] sphere tests
  * [8] units handed out [9] wave-level inner-step trips [10] wave-level leaf-step trips [11..12] their cycles (stamps build). */

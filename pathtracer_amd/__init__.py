@@ -22,7 +22,7 @@ PRIM_MISS = -(2 ** 31)
 # Every symbol include/pt_hip.h declares (tests/test_abi.py checks the library exports exactly these).
 EXPORTS = (
     "pt_hip_device_count", "pt_hip_create", "pt_hip_destroy", "pt_hip_strerror", "pt_hip_last_error",
-    "pt_hip_upload_scene", "pt_hip_render", "pt_hip_render_device", "pt_hip_last_stats", "pt_hip_debug_counters", "pt_hip_resolve_device",
+    "pt_hip_upload_scene", "pt_hip_render", "pt_hip_render_device", "pt_hip_last_stats", "pt_hip_debug_counters", "pt_chunk_schedule", "pt_hip_resolve_device",
     "pt_resolve", "pt_pack_bgra", "pt_bmp_write", "pt_bmp_write_bgra", "pt_bmp_header",
     "pt_scene_builtin", "pt_scene_get_desc", "pt_scene_free",
     "pt_hip_probe_primitives", "pt_hip_probe_hits", "pt_hip_probe_get_rays", "pt_hip_probe_scatter", "pt_hip_probe_paths",
@@ -91,6 +91,8 @@ def load_library(path=LIB_PATH):
     L.pt_hip_render_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]
     L.pt_hip_last_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.pt_hip_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 16)]
+    L.pt_chunk_schedule.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]
+    L.pt_chunk_schedule.restype = C.c_uint32
     L.pt_hip_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
@@ -310,6 +312,15 @@ class Renderer:
 
 
 # ---- host-only helpers (no GPU needed) -----------------------------------------------------------------------
+def chunk_schedule(nspp, ratio_q16, min_spp):
+    """The sample-chunk sizes the render kernel walks (host-only; see include/pt_hip.h)."""
+    L = load_library()
+    n = L.pt_chunk_schedule(nspp, ratio_q16, min_spp, None, 0)
+    out = (C.c_uint32 * max(1, n))()
+    L.pt_chunk_schedule(nspp, ratio_q16, min_spp, out, n)
+    return list(out)[:n]
+
+
 def resolve(sum_rgba, spp_total):
     s = _f32(sum_rgba)
     out = np.empty_like(s)

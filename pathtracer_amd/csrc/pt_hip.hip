@@ -684,12 +684,12 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         st = upload_f4(ctx, bv.mat.data(), bv.mat.size() * 4, &ctx->mat_dev); if (st != PT_OK) return st;
         fill_scene_args(&ctx->sc_bvh, ctx->blob_planes, ctx->blob_planes_dev, d, d->n_planes);
         ctx->sc_bvh.bvh = BvhView{ctx->nodes_dev, ctx->sph_dev, ctx->vel_dev, ctx->mat_dev, bv.root_ref, bv.n_spheres};
-        ctx->sc_bvh.stack_entries = bv.depth + 2 < 4 ? 4 : bv.depth + 2; // sentinel + one entry per level
+        ctx->sc_bvh.stack_entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1; // the sentinel + at most one pushed sibling per inner node of a root-to-leaf path (bv.depth of them)
         ctx->sc_bvh.leaf_batch = kLeafBatch;
         if (const char* e = getenv("PT_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->sc_bvh.leaf_batch = (uint32_t)v; } // tuning experiments only
         ctx->bvh_nodes = bv.n_nodes; ctx->bvh_depth = bv.depth;
         ctx->moving = bv.moving;
-        if (bv.depth + 2 > kBvhStack) { ctx->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
+        if (bv.depth + 1 > kBvhStack) { ctx->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
         // (3) the same tree staged in LDS behind the planes, when planes + tree + payload + 4 waves' stacks fit
         const uint32_t entries = ctx->sc_bvh.stack_entries;
         // Materials are read once per hit, the tree and the spheres at every step: only the latter are worth LDS, and
@@ -873,6 +873,19 @@ int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out)
     }
     *out = ctx->last;
     return PT_OK;
+}
+
+uint32_t pt_chunk_schedule(uint32_t nspp, uint32_t ratio_q16, uint32_t min_spp, uint32_t* out_sizes, uint32_t cap)
+{
+    if (min_spp == 0) min_spp = 1;
+    uint32_t n = 0;
+    for (uint32_t s0 = 0; s0 < nspp; ++n)
+    {
+        const uint32_t u = chunk_size(nspp - s0, ratio_q16, min_spp);
+        if (out_sizes && n < cap) out_sizes[n] = u;
+        s0 += u;
+    }
+    return n;
 }
 
 int pt_hip_debug_counters(pt_ctx* ctx, uint64_t out16[16])

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_exactly_the_header(golden_dir):
     header = open(os.path.join(ROOT, "include", "pt_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|void|const char\*|pt_scene\*)\s+(pt_[a-z0-9_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|void|uint32_t|const char\*|pt_scene\*)\s+(pt_[a-z0-9_]+)\s*\(", header, re.M))
     assert declared == set(pt.EXPORTS), declared ^ set(pt.EXPORTS)
     L = pt.load_library()
     for sym in pt.EXPORTS:
@@ -113,3 +113,24 @@ def test_product_never_touches_the_oracle():
     so = pt.LIB_PATH
     needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
     assert "oracle" not in needed and "ptref" not in needed
+
+
+def test_chunk_schedule_partitions_the_sample_range():
+    """The guided schedule the render kernel walks (host-only helper): sizes sum to nspp, respect the minimum (a last
+    remainder below 2 x min goes in one piece), never exceed half of what is left, and shrink monotonically."""
+    rng = np.random.default_rng(2)
+    cases = [(1, 0x8000, 8), (7, 0x8000, 8), (15, 0x8000, 8), (16, 0x8000, 8), (512, 0x8000, 8), (512, 0x1000, 8), (4096, 0, 8), (4096, 123, 1)]
+    cases += [(int(rng.integers(1, 100000)), int(rng.integers(0, 0x8001)), int(rng.integers(1, 64))) for _ in range(200)]
+    for nspp, ratio, m in cases:
+        sizes = pt.chunk_schedule(nspp, ratio, m)
+        assert sum(sizes) == nspp and all(s > 0 for s in sizes), (nspp, ratio, m)
+        left = nspp
+        for i, s in enumerate(sizes):
+            if left < 2 * m:
+                assert s == left and i == len(sizes) - 1
+            else:
+                assert m <= s <= max(m, left // 2)
+            left -= s
+        assert all(a >= b for a, b in zip(sizes[:-2], sizes[1:-1]))          # big first (the last piece may be the remainder)
+    assert pt.chunk_schedule(512, 0x8000, 8) == [256, 128, 64, 32, 16, 8, 8]
+    assert pt.chunk_schedule(0, 0x8000, 8) == []

@@ -10,11 +10,19 @@ HOST     := pathtracer_amd/host
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Wall
 
-all: lib oracle
+BINDIR   := pathtracer_amd/bin
+
+all: lib cli oracle
 
 lib: $(LIBDIR)/libpt_hip.so
 
-$(LIBDIR)/pt_hip.o: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h include/pt_hip.h
+# pt_render: the reference's main() as a command-line tool over the C-ABI (links against nothing but libpt_hip.so)
+cli: $(BINDIR)/pt_render
+$(BINDIR)/pt_render: $(HOST)/pt_main.cpp include/pt_hip.h $(LIBDIR)/libpt_hip.so
+	@mkdir -p $(BINDIR)
+	g++ -O2 -std=c++17 -Wall $< -o $@ -L$(LIBDIR) -lpt_hip -pthread -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,/opt/rocm/lib
+
+$(LIBDIR)/pt_hip.o: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h $(CSRC)/pt_bvh.h include/pt_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -33,9 +41,9 @@ isa: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h
 	$(HIPCC) $(HIPFLAGS) -save-temps=obj -Rpass-analysis=kernel-resource-usage -c $< -o $(LIBDIR)/isa/pt_hip.o 2> $(LIBDIR)/isa/resource_usage.txt || (cat $(LIBDIR)/isa/resource_usage.txt; false)
 
 clean:
-	rm -rf $(LIBDIR) ; $(MAKE) -C oracle clean
+	rm -rf $(LIBDIR) $(BINDIR) ; $(MAKE) -C oracle clean
 
-.PHONY: all lib oracle isa clean
+.PHONY: all lib cli oracle isa clean
 
 # Diagnostic build with in-kernel s_memtime stamps (never shipped, never benchmarked: read its SHARES, not its speed).
 stamps: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h $(LIBDIR)/pt_world.o

@@ -151,6 +151,11 @@ int pt_bmp_header(uint32_t width, uint32_t height, uint8_t* out58);
 pt_scene* pt_scene_builtin(int scene_id, float aspect_ratio, uint32_t n_spheres_for_id5);
 int pt_scene_get_desc(const pt_scene* scene, pt_scene_desc* out);
 void pt_scene_free(pt_scene* scene);
+/* Scene files.  The reference hard-codes its scene as a function call (src/main.cpp:396) and its
+ * settings as macros (src/main.cpp:29-42); these two give the same World + Camera a text form (format: pt_world.cpp),
+ * exact to the bit for every float.  pt_scene_load returns NULL on a missing or malformed file. */
+int pt_scene_save(const pt_scene_desc* scene, const char* path);
+pt_scene* pt_scene_load(const char* path);
 
 /* ---- parity probes: the product's own device functions on caller-supplied inputs ---------------------- */
 /* All pointers are HOST pointers; n records; synchronous.  They run the same device code as the render kernels

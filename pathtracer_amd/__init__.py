@@ -24,7 +24,7 @@ EXPORTS = (
     "pt_hip_device_count", "pt_hip_create", "pt_hip_destroy", "pt_hip_strerror", "pt_hip_last_error",
     "pt_hip_upload_scene", "pt_hip_render", "pt_hip_render_device", "pt_hip_last_stats", "pt_hip_debug_counters", "pt_chunk_schedule", "pt_hip_resolve_device",
     "pt_resolve", "pt_pack_bgra", "pt_bmp_write", "pt_bmp_write_bgra", "pt_bmp_header",
-    "pt_scene_builtin", "pt_scene_get_desc", "pt_scene_free",
+    "pt_scene_builtin", "pt_scene_get_desc", "pt_scene_free", "pt_scene_save", "pt_scene_load",
     "pt_hip_probe_primitives", "pt_hip_probe_hits", "pt_hip_probe_get_rays", "pt_hip_probe_scatter", "pt_hip_probe_paths",
     "pt_hip_probe_samples", "pt_hip_probe_philox",
 )
@@ -84,6 +84,9 @@ def load_library(path=LIB_PATH):
     L.pt_scene_builtin.argtypes = [C.c_int, C.c_float, C.c_uint32]
     L.pt_scene_get_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
     L.pt_scene_free.argtypes = [C.c_void_p]
+    L.pt_scene_save.argtypes = [C.POINTER(SceneDesc), C.c_char_p]
+    L.pt_scene_load.argtypes = [C.c_char_p]
+    L.pt_scene_load.restype = C.c_void_p
     L.pt_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.pt_hip_destroy.argtypes = [C.c_void_p]
     L.pt_hip_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
@@ -155,12 +158,10 @@ class Scene:
         return len(self.pl_n_d)
 
     @staticmethod
-    def builtin(scene_id, aspect, n_spheres=0):
-        """init_test_scene_{1,2,3} / materials (4) / random spheres (5) via the library's host-side builders."""
+    def _from_handle(h, what):
         L = load_library()
-        h = L.pt_scene_builtin(scene_id, aspect, n_spheres)
         if not h:
-            raise PtError(PT_ERR_INVALID, f"pt_scene_builtin({scene_id})")
+            raise PtError(PT_ERR_INVALID, what)
         try:
             d = SceneDesc()
             st = L.pt_scene_get_desc(h, C.byref(d))
@@ -180,6 +181,21 @@ class Scene:
                          arr(d.plane_mat_param, 2 * npl, np.float32), d.t0, d.t1, np.array(list(d.camera), np.float32))
         finally:
             L.pt_scene_free(h)
+
+    @staticmethod
+    def builtin(scene_id, aspect, n_spheres=0):
+        """init_test_scene_{1,2,3} / materials (4) / random spheres (5) via the library's host-side builders."""
+        return Scene._from_handle(load_library().pt_scene_builtin(scene_id, aspect, n_spheres), f"pt_scene_builtin({scene_id})")
+
+    @staticmethod
+    def load(path):
+        """A scene file written by save() / pt_scene_save (text; format in pathtracer_amd/host/pt_world.cpp)."""
+        return Scene._from_handle(load_library().pt_scene_load(os.fsencode(path)), f"pt_scene_load({path})")
+
+    def save(self, path):
+        st = load_library().pt_scene_save(C.byref(self.desc), os.fsencode(path))
+        if st != PT_OK:
+            raise PtError(st, f"pt_scene_save({path})")
 
 
 def device_count():

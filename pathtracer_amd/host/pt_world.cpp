@@ -301,6 +301,90 @@ int pt_scene_get_desc(const pt_scene* s, pt_scene_desc* out)
 
 void pt_scene_free(pt_scene* s) { delete s; }
 
+// ---- scene files (the reference hard-codes its scene call, main.cpp:396) --------------------
+// Text, one record per line, '#' comments; floats are written with 9 significant digits (round-trips f32 exactly):
+//   pt_scene 1
+//   time   t0 t1
+//   camera px py pz  dx dy dz  ux uy uz  fov aspect focus lensRadius
+//   sphere x y z r  vx vy vz  type  r g b a  roughness n
+//   plane  nx ny nz d  type  r g b a  roughness n
+int pt_scene_save(const pt_scene_desc* d, const char* path)
+{
+    if (!d || !path) return PT_ERR_INVALID;
+    FILE* f = fopen(path, "w");
+    if (!f) return PT_ERR_IO;
+    fprintf(f, "pt_scene 1\n# %u spheres, %u planes\ntime %.9g %.9g\ncamera", d->n_spheres, d->n_planes, d->t0, d->t1);
+    for (int k = 0; k < 13; ++k) fprintf(f, " %.9g", d->camera[k]);
+    fprintf(f, "\n");
+    for (uint32_t i = 0; i < d->n_planes; ++i)
+    {
+        const float* p = d->plane_n_d + 4 * (size_t)i; const float* c = d->plane_mat_rgba + 4 * (size_t)i; const float* q = d->plane_mat_param + 2 * (size_t)i;
+        fprintf(f, "plane %.9g %.9g %.9g %.9g %u %.9g %.9g %.9g %.9g %.9g %.9g\n", p[0], p[1], p[2], p[3], d->plane_mat_type[i], c[0], c[1], c[2], c[3], q[0], q[1]);
+    }
+    for (uint32_t i = 0; i < d->n_spheres; ++i)
+    {
+        const float* p = d->sphere_pos_r + 4 * (size_t)i; const float* c = d->sphere_mat_rgba + 4 * (size_t)i; const float* q = d->sphere_mat_param + 2 * (size_t)i;
+        const float zero[3] = {0, 0, 0};
+        const float* v = d->sphere_vel ? d->sphere_vel + 3 * (size_t)i : zero;
+        fprintf(f, "sphere %.9g %.9g %.9g %.9g %.9g %.9g %.9g %u %.9g %.9g %.9g %.9g %.9g %.9g\n", p[0], p[1], p[2], p[3], v[0], v[1], v[2],
+                d->sphere_mat_type[i], c[0], c[1], c[2], c[3], q[0], q[1]);
+    }
+    const bool ok = !ferror(f);
+    return (fclose(f) == 0 && ok) ? PT_OK : PT_ERR_IO;
+}
+
+pt_scene* pt_scene_load(const char* path)
+{
+    if (!path) return nullptr;
+    FILE* f = fopen(path, "r");
+    if (!f) return nullptr;
+    pt_scene* s = new (std::nothrow) pt_scene();
+    if (!s) { fclose(f); return nullptr; }
+    pt::FlatScene& fl = s->flat;
+    pt_scene_desc& d = fl.desc;
+    bool ok = true, header = false, haveCamera = false, moving = false;
+    char line[1024];
+    while (ok && fgets(line, sizeof line, f))
+    {
+        char* p = line;
+        while (*p == ' ' || *p == '\t') ++p;
+        if (*p == '#' || *p == '\n' || *p == '\r' || *p == 0) continue;
+        char word[16]; int used = 0;
+        if (sscanf(p, "%15s%n", word, &used) != 1) { ok = false; break; }
+        p += used;
+        float v[14]; unsigned type = 0;
+        auto floats = [&](int n, float* out) { for (int k = 0; k < n; ++k) { char* e; out[k] = strtof(p, &e); if (e == p) return false; p = e; } return true; };
+        auto uint = [&](unsigned* out) { char* e; unsigned long u = strtoul(p, &e, 10); if (e == p) return false; p = e; *out = (unsigned)u; return true; };
+        if (!strcmp(word, "pt_scene")) { unsigned ver = 0; ok = uint(&ver) && ver == 1; header = ok; }
+        else if (!header) ok = false;
+        else if (!strcmp(word, "time")) { ok = floats(2, v); d.t0 = v[0]; d.t1 = v[1]; }
+        else if (!strcmp(word, "camera")) { ok = floats(13, d.camera); haveCamera = ok; }
+        else if (!strcmp(word, "plane"))
+        {
+            ok = floats(4, v) && uint(&type) && floats(6, v + 4) && type <= PT_MAT_DIALECTRIC;
+            if (ok) { fl.pl_n_d.insert(fl.pl_n_d.end(), v, v + 4); fl.pl_type.push_back(type); fl.pl_rgba.insert(fl.pl_rgba.end(), v + 4, v + 8); fl.pl_param.insert(fl.pl_param.end(), v + 8, v + 10); }
+        }
+        else if (!strcmp(word, "sphere"))
+        {
+            ok = floats(7, v) && uint(&type) && floats(6, v + 7) && type <= PT_MAT_DIALECTRIC;
+            if (ok)
+            {
+                fl.pos_r.insert(fl.pos_r.end(), v, v + 4); fl.vel.insert(fl.vel.end(), v + 4, v + 7); fl.type.push_back(type);
+                fl.rgba.insert(fl.rgba.end(), v + 7, v + 11); fl.param.insert(fl.param.end(), v + 11, v + 13);
+                moving = moving || v[4] != 0 || v[5] != 0 || v[6] != 0;
+            }
+        }
+        else ok = false;
+    }
+    fclose(f);
+    if (!ok || !header || !haveCamera) { delete s; return nullptr; }
+    d.n_spheres = (uint32_t)fl.type.size(); d.n_planes = (uint32_t)fl.pl_type.size();
+    d.sphere_pos_r = fl.pos_r.data(); d.sphere_vel = moving ? fl.vel.data() : nullptr; d.sphere_mat_type = fl.type.data();
+    d.sphere_mat_rgba = fl.rgba.data(); d.sphere_mat_param = fl.param.data();
+    d.plane_n_d = fl.pl_n_d.data(); d.plane_mat_type = fl.pl_type.data(); d.plane_mat_rgba = fl.pl_rgba.data(); d.plane_mat_param = fl.pl_param.data();
+    return s;
+}
+
 int pt_resolve(const float* sum, uint32_t n, uint32_t spp, float* out)                       // main.cpp:358
 {
     if (!sum || !out || spp == 0) return PT_ERR_INVALID;

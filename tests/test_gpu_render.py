@@ -241,3 +241,28 @@ def test_converged_image_vs_reference_renderer(renderer, golden_dir):
         print(f"{key}: PSNR {p:.2f} dB (floor {floor_psnr:.2f}), mean rel err {m:.5f} (floor {floor_mre:.5f})")
         assert p >= 40.0, (key, p, floor_psnr)
         assert m <= floor_mre * 1.5, (key, m, floor_mre)
+
+
+def test_command_line_renderer_matches_the_library(renderer, tmp_path):
+    """pathtracer_amd/bin/pt_render (the reference's main() as a tool): the BMP it writes is byte-identical to the one
+    the same settings give through the C-ABI from Python, also when the scene goes through a scene file."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(pt.LIB_PATH), "..", "bin", "pt_render")
+    if not os.path.exists(exe):
+        pytest.fail("pathtracer_amd/bin/pt_render is not built (make cli)")
+    w, h, spp, depth, seed = 96, 54, 6, 8, 5
+    out1, out2, sfile = tmp_path / "a.bmp", tmp_path / "b.bmp", tmp_path / "scene.txt"
+    common = ["--width", str(w), "--height", str(h), "--spp", str(spp), "--depth", str(depth), "--seed", str(seed)]
+    r1 = subprocess.run([exe, "--scene", "1", "--save-scene", str(sfile), "--out", str(out1)] + common, capture_output=True, text=True, timeout=120)
+    assert r1.returncode == 0, r1.stderr
+    assert "Time elapsed" in r1.stdout
+    r2 = subprocess.run([exe, "--scene-file", str(sfile), "--out", str(out2)] + common, capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 0, r2.stderr
+    renderer.upload(pt.Scene.builtin(1, w / h))
+    px = pt.resolve(renderer.render(w, h, 0, spp, depth, seed=seed), spp)
+    expect = bytes(pt.bmp_header(w, h)) + pt.pack_bgra(px).astype("<u4").tobytes()
+    assert out1.read_bytes() == expect
+    assert out2.read_bytes() == expect
+    bad = subprocess.run([exe, "--spp", "0"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2

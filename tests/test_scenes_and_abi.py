@@ -134,3 +134,26 @@ def test_chunk_schedule_partitions_the_sample_range():
         assert all(a >= b for a, b in zip(sizes[:-2], sizes[1:-1]))          # big first (the last piece may be the remainder)
     assert pt.chunk_schedule(512, 0x8000, 8) == [256, 128, 64, 32, 16, 8, 8]
     assert pt.chunk_schedule(0, 0x8000, 8) == []
+
+
+def test_scene_files_round_trip_exactly(tmp_path):
+    """pt_scene_save / pt_scene_load: every float of every built-in scene survives the text form."""
+    for sid, n in ((1, 0), (2, 0), (3, 0), (4, 0), (5, 300)):
+        a = pt.Scene.builtin(sid, 16 / 9, n)
+        f = tmp_path / f"scene{sid}.txt"
+        a.save(str(f))
+        b = pt.Scene.load(str(f))
+        assert a.n_spheres == b.n_spheres and a.n_planes == b.n_planes
+        for name in ("pos_r", "mtype", "rgba", "param", "pl_n_d", "pl_type", "pl_rgba", "pl_param", "camera"):
+            x, y = getattr(a, name), getattr(b, name)
+            assert x.dtype == y.dtype and np.array_equal(x.view(np.uint32), y.view(np.uint32)), (sid, name)
+        assert (a.vel is None) == (b.vel is None) and (a.vel is None or bit_equal(a.vel, b.vel)), sid
+        assert (a.t0, a.t1) == (b.t0, b.t1)
+    bad = tmp_path / "bad.txt"
+    for text in ("", "sphere 0 0 0 1 0 0 0 1 1 1 1 1 0 0\n", "pt_scene 2\n", "pt_scene 1\ncamera 1 2 3\n", "pt_scene 1\ntime 0 1\n",
+                 "pt_scene 1\ncamera 0 0 0 0 0 -1 0 1 0 1 1 1 0\nsphere 0 0 0 1 0 0 0 9 1 1 1 1 0 0\n", "pt_scene 1\nbogus 1\n"):
+        bad.write_text(text)
+        with pytest.raises(pt.PtError):
+            pt.Scene.load(str(bad))
+    with pytest.raises(pt.PtError):
+        pt.Scene.load(str(tmp_path / "missing.txt"))

@@ -16,7 +16,11 @@
 #include <stdint.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
+#include <atomic>
+#include <functional>
+#include <thread>
 #include <vector>
 
 #include "../../include/pt_hip.h"
@@ -89,100 +93,153 @@ inline void build_bvh(const pt_scene_desc* d, BvhData* out)
     std::vector<uint32_t> idx(n);
     for (uint32_t i = 0; i < n; ++i) idx[i] = i;
 
-    struct Task { uint32_t begin, end, parent, side, depth; }; // parent node index, side 0 = left ref, 1 = right ref
-    std::vector<Task> stack;
+    // ---- top-down binned-SAH build.  One split = centroid bounds -> 16 bins x 3 axes -> best plane -> partition of idx.
+    // Parallel in two ways (worker count = PT_BUILD_THREADS, else min(hardware threads, 16)): the passes over a BIG range
+    // (the top of the tree) are cut into per-thread slices; once the frontier holds enough subtrees they are built
+    // independently, each into its own node array, and spliced into the final array afterwards.
+    struct Task { uint32_t begin, end, parent, side, depth; }; // parent = node index in the SAME array (or kNoParent), side 0/1
+    constexpr uint32_t kNoParent = 0xFFFFFFFFu;
+    constexpr int NB = 16;
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads == 0) nthreads = 1;
+    if (nthreads > 16) nthreads = 16;
+    if (const char* e = getenv("PT_BUILD_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) nthreads = (unsigned)v; }
+    if (n < 65536) nthreads = 1;
     out->nodes.clear();
     out->depth = 0;
     auto make_leaf_ref = [](uint32_t begin, uint32_t count) { return kLeafFlag | ((count - 1u) << 28) | begin; };
     auto range_box = [&](uint32_t b, uint32_t e) { Aabb r; aabb_reset(r); for (uint32_t i = b; i < e; ++i) aabb_grow(r, box[idx[i]]); return r; };
-    auto set_child = [&](uint32_t parent, uint32_t side, uint32_t ref, const Aabb& bx) {
-        float* nd = out->nodes.data() + 16 * (size_t)parent;
+    auto set_child = [](std::vector<float>& nodes, uint32_t parent, uint32_t side, uint32_t ref, const Aabb& bx) {
+        float* nd = nodes.data() + 16 * (size_t)parent;
         if (side == 0) { nd[0] = bx.lo[0]; nd[1] = bx.lo[1]; nd[2] = bx.lo[2]; nd[3] = bx.hi[0]; nd[4] = bx.hi[1]; nd[5] = bx.hi[2]; nd[12] = u2f(ref); }
         else { nd[6] = bx.lo[0]; nd[7] = bx.lo[1]; nd[8] = bx.lo[2]; nd[9] = bx.hi[0]; nd[10] = bx.hi[1]; nd[11] = bx.hi[2]; nd[13] = u2f(ref); }
+    };
+    // run f(slice_begin, slice_end, slice_index) over [b, e) on `workers` threads (1 = inline)
+    auto parallel_slices = [&](uint32_t b, uint32_t e, unsigned workers, const std::function<void(uint32_t, uint32_t, unsigned)>& f) {
+        if (workers <= 1 || e - b < 32768) { f(b, e, 0); return 1u; }
+        std::vector<std::thread> th;
+        const uint64_t len = e - b;
+        for (unsigned w = 0; w < workers; ++w) th.emplace_back(f, b + (uint32_t)(len * w / workers), b + (uint32_t)(len * (w + 1) / workers), w);
+        for (auto& t : th) t.join();
+        return workers;
+    };
+    struct Bins { Aabb bb[3][NB]; uint32_t bc[3][NB]; float clo[3], chi[3]; };
+    // One split of task t inside node array `nodes`: allocates the inner node, links it to its parent, partitions idx and
+    // appends the (up to two) child tasks to `todo`.  `workers` > 1 slices the big passes.
+    auto split = [&](const Task& t, std::vector<float>& nodes, std::vector<Task>& todo, uint32_t* maxDepth, unsigned workers) {
+        if (t.depth > *maxDepth) *maxDepth = t.depth;
+        const uint32_t count = t.end - t.begin;
+        const uint32_t self = (uint32_t)(nodes.size() / 16);
+        nodes.resize(nodes.size() + 16, 0.0f);
+        if (t.parent != kNoParent) set_child(nodes, t.parent, t.side, self, range_box(t.begin, t.end));
+        // centroid bounds
+        std::vector<Bins> part(workers > 1 ? workers : 1);
+        unsigned used = parallel_slices(t.begin, t.end, workers, [&](uint32_t b, uint32_t e, unsigned w) {
+            Bins& P = part[w];
+            for (int k = 0; k < 3; ++k) { P.clo[k] = 3e38f; P.chi[k] = -3e38f; }
+            for (uint32_t i = b; i < e; ++i)
+                for (int k = 0; k < 3; ++k) { float c = cen[3 * (size_t)idx[i] + k]; if (c < P.clo[k]) P.clo[k] = c; if (c > P.chi[k]) P.chi[k] = c; }
+        });
+        float clo[3] = {3e38f, 3e38f, 3e38f}, chi[3] = {-3e38f, -3e38f, -3e38f};
+        for (unsigned w = 0; w < used; ++w) for (int k = 0; k < 3; ++k) { if (part[w].clo[k] < clo[k]) clo[k] = part[w].clo[k]; if (part[w].chi[k] > chi[k]) chi[k] = part[w].chi[k]; }
+        float scale[3];
+        for (int k = 0; k < 3; ++k) scale[k] = chi[k] - clo[k] > 0 ? NB / (chi[k] - clo[k]) : 0.0f;
+        auto bin_of = [&](uint32_t i, int k) { int b2 = (int)((cen[3 * (size_t)i + k] - clo[k]) * scale[k]); if (b2 >= NB) b2 = NB - 1; if (b2 < 0) b2 = 0; return b2; };
+        // binning, all three axes in one pass
+        used = parallel_slices(t.begin, t.end, workers, [&](uint32_t b, uint32_t e, unsigned w) {
+            Bins& P = part[w];
+            for (int k = 0; k < 3; ++k) for (int b2 = 0; b2 < NB; ++b2) { aabb_reset(P.bb[k][b2]); P.bc[k][b2] = 0; }
+            for (uint32_t i = b; i < e; ++i)
+                for (int k = 0; k < 3; ++k) { if (scale[k] == 0.0f) continue; const int b2 = bin_of(idx[i], k); aabb_grow(P.bb[k][b2], box[idx[i]]); ++P.bc[k][b2]; }
+        });
+        for (unsigned w = 1; w < used; ++w)
+            for (int k = 0; k < 3; ++k) for (int b2 = 0; b2 < NB; ++b2) { aabb_grow(part[0].bb[k][b2], part[w].bb[k][b2]); part[0].bc[k][b2] += part[w].bc[k][b2]; }
+        int bestAxis = -1, bestBin = -1; float bestCost = 3e38f;
+        for (int k = 0; k < 3; ++k)
+        {
+            if (scale[k] == 0.0f) continue;
+            const Aabb* bb = part[0].bb[k]; const uint32_t* bc = part[0].bc[k];
+            float rightArea[NB]; uint32_t rightCount[NB];
+            Aabb acc; aabb_reset(acc); uint32_t cnt = 0;
+            for (int b2 = NB - 1; b2 > 0; --b2) { aabb_grow(acc, bb[b2]); cnt += bc[b2]; rightArea[b2] = aabb_area(acc); rightCount[b2] = cnt; }
+            aabb_reset(acc); cnt = 0;
+            for (int b2 = 0; b2 < NB - 1; ++b2)
+            {
+                aabb_grow(acc, bb[b2]); cnt += bc[b2];
+                if (cnt == 0 || rightCount[b2 + 1] == 0) continue;
+                float cost = aabb_area(acc) * cnt + rightArea[b2 + 1] * rightCount[b2 + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = k; bestBin = b2; }
+            }
+        }
+        uint32_t mid = t.begin; // (stays there when all centroids coincide)
+        if (bestAxis >= 0)
+        {
+            const int k = bestAxis;
+            uint32_t* m = std::partition(idx.data() + t.begin, idx.data() + t.end, [&](uint32_t i) { return bin_of(i, k) <= bestBin; });
+            mid = (uint32_t)(m - idx.data());
+        }
+        if (mid == t.begin || mid == t.end) // no useful plane: median split along the widest axis
+        {
+            mid = t.begin + count / 2;
+            int k = 0; float e = -1;
+            for (int a = 0; a < 3; ++a) if (chi[a] - clo[a] > e) { e = chi[a] - clo[a]; k = a; }
+            std::nth_element(idx.begin() + t.begin, idx.begin() + mid, idx.begin() + t.end,
+                             [&](uint32_t a, uint32_t b2) { return cen[3 * (size_t)a + k] < cen[3 * (size_t)b2 + k]; });
+        }
+        const uint32_t rng[2][2] = {{t.begin, mid}, {mid, t.end}};
+        for (int side = 1; side >= 0; --side) // right first: the left subtree is laid out next (depth-first)
+        {
+            const uint32_t b2 = rng[side][0], e = rng[side][1];
+            if (e - b2 <= kLeafMax) set_child(nodes, self, (uint32_t)side, make_leaf_ref(b2, e - b2), range_box(b2, e));
+            else todo.push_back({b2, e, self, (uint32_t)side, t.depth + 1});
+        }
     };
     if (n == 0) { out->root_ref = kLeafFlag; out->n_nodes = 0; return; } // leaf of "1 sphere at 0" is never used: n_spheres == 0 short-cuts
     if (n <= kLeafMax) { out->root_ref = make_leaf_ref(0, n); }
     else
     {
-        out->nodes.resize(16, 0.0f); // root inner node = node 0
-        out->root_ref = 0;
-        stack.push_back({0, n, 0xFFFFFFFFu, 0, 1});
-        while (!stack.empty())
+        out->root_ref = 0; // root inner node = node 0
+        std::vector<Task> frontier;
+        frontier.push_back({0, n, kNoParent, 0, 1});
+        // phase A: split the biggest frontier task (sliced passes) until there are enough subtrees for everyone
+        while (nthreads > 1 && frontier.size() < 4 * (size_t)nthreads)
         {
-            Task t = stack.back();
-            stack.pop_back();
-            if (t.depth > out->depth) out->depth = t.depth;
-            const uint32_t count = t.end - t.begin;
-            uint32_t self; // index of the inner node for this range
-            if (t.parent == 0xFFFFFFFFu) self = 0;
-            else
-            {
-                self = (uint32_t)(out->nodes.size() / 16);
-                out->nodes.resize(out->nodes.size() + 16, 0.0f);
-                set_child(t.parent, t.side, self, range_box(t.begin, t.end));
-            }
-            // binned SAH over the centroid bounds (16 bins, best of 3 axes); falls back to a median split
-            float clo[3] = {3e38f, 3e38f, 3e38f}, chi[3] = {-3e38f, -3e38f, -3e38f};
-            for (uint32_t i = t.begin; i < t.end; ++i)
-                for (int k = 0; k < 3; ++k) { float c = cen[3 * (size_t)idx[i] + k]; if (c < clo[k]) clo[k] = c; if (c > chi[k]) chi[k] = c; }
-            int bestAxis = -1, bestBin = -1; float bestCost = 3e38f;
-            const int NB = 16;
-            for (int k = 0; k < 3; ++k)
-            {
-                const float ext = chi[k] - clo[k];
-                if (!(ext > 0)) continue;
-                Aabb bb[NB]; uint32_t bc[NB];
-                for (int b2 = 0; b2 < NB; ++b2) { aabb_reset(bb[b2]); bc[b2] = 0; }
-                const float scale = NB / ext;
-                for (uint32_t i = t.begin; i < t.end; ++i)
-                {
-                    int b2 = (int)((cen[3 * (size_t)idx[i] + k] - clo[k]) * scale);
-                    if (b2 >= NB) b2 = NB - 1;
-                    if (b2 < 0) b2 = 0;
-                    aabb_grow(bb[b2], box[idx[i]]); ++bc[b2];
-                }
-                float rightArea[NB]; uint32_t rightCount[NB];
-                Aabb acc; aabb_reset(acc); uint32_t cnt = 0;
-                for (int b2 = NB - 1; b2 > 0; --b2) { aabb_grow(acc, bb[b2]); cnt += bc[b2]; rightArea[b2] = aabb_area(acc); rightCount[b2] = cnt; }
-                aabb_reset(acc); cnt = 0;
-                for (int b2 = 0; b2 < NB - 1; ++b2)
-                {
-                    aabb_grow(acc, bb[b2]); cnt += bc[b2];
-                    if (cnt == 0 || rightCount[b2 + 1] == 0) continue;
-                    float cost = aabb_area(acc) * cnt + rightArea[b2 + 1] * rightCount[b2 + 1];
-                    if (cost < bestCost) { bestCost = cost; bestAxis = k; bestBin = b2; }
-                }
-            }
-            uint32_t mid;
-            if (bestAxis >= 0)
-            {
-                const int k = bestAxis;
-                const float scale = NB / (chi[k] - clo[k]);
-                uint32_t* first = idx.data() + t.begin; uint32_t* last = idx.data() + t.end;
-                uint32_t* m = std::partition(first, last, [&](uint32_t i) {
-                    int b2 = (int)((cen[3 * (size_t)i + k] - clo[k]) * scale);
-                    if (b2 >= NB) b2 = NB - 1;
-                    if (b2 < 0) b2 = 0;
-                    return b2 <= bestBin; });
-                mid = (uint32_t)(m - idx.data());
-            }
-            else
-                mid = t.begin; // all centroids coincide
-            if (mid == t.begin || mid == t.end)
-            {
-                mid = t.begin + count / 2;
-                int k = 0; float e = -1;
-                for (int a = 0; a < 3; ++a) if (chi[a] - clo[a] > e) { e = chi[a] - clo[a]; k = a; }
-                std::nth_element(idx.begin() + t.begin, idx.begin() + mid, idx.begin() + t.end,
-                                 [&](uint32_t a, uint32_t b2) { return cen[3 * (size_t)a + k] < cen[3 * (size_t)b2 + k]; });
-            }
-            const uint32_t rng[2][2] = {{t.begin, mid}, {mid, t.end}};
-            for (int side = 1; side >= 0; --side) // push right first so the left subtree is laid out next (depth-first)
-            {
-                const uint32_t b2 = rng[side][0], e = rng[side][1];
-                if (e - b2 <= kLeafMax) set_child(self, (uint32_t)side, make_leaf_ref(b2, e - b2), range_box(b2, e));
-                else stack.push_back({b2, e, self, (uint32_t)side, t.depth + 1});
-            }
+            size_t big = 0;
+            for (size_t i = 1; i < frontier.size(); ++i) if (frontier[i].end - frontier[i].begin > frontier[big].end - frontier[big].begin) big = i;
+            if (frontier[big].end - frontier[big].begin < 4096) break;
+            const Task t = frontier[big];
+            frontier.erase(frontier.begin() + (long)big);
+            split(t, out->nodes, frontier, &out->depth, nthreads);
+        }
+        // phase B: every frontier task is an independent subtree
+        struct Sub { std::vector<float> nodes; uint32_t depth = 0; };
+        std::vector<Sub> subs(frontier.size());
+        auto build_sub = [&](size_t j) {
+            std::vector<Task> stack;
+            Task root = frontier[j]; root.parent = kNoParent;
+            stack.push_back(root);
+            while (!stack.empty()) { const Task t = stack.back(); stack.pop_back(); split(t, subs[j].nodes, stack, &subs[j].depth, 1); }
+        };
+        if (nthreads > 1)
+        {
+            std::atomic<size_t> next{0};
+            std::vector<std::thread> th;
+            for (unsigned w = 0; w < nthreads; ++w) th.emplace_back([&]() { for (size_t j; (j = next.fetch_add(1)) < frontier.size();) build_sub(j); });
+            for (auto& t : th) t.join();
+        }
+        else
+            for (size_t j = 0; j < frontier.size(); ++j) build_sub(j);
+        // splice: a subtree's inner references move by its base index; its root is hooked into the phase-A node
+        for (size_t j = 0; j < frontier.size(); ++j)
+        {
+            const uint32_t base = (uint32_t)(out->nodes.size() / 16);
+            std::vector<float>& sn = subs[j].nodes;
+            for (size_t k = 0; k < sn.size(); k += 16)
+                for (int c = 12; c <= 13; ++c) { const uint32_t ref = f2u(sn[k + c]); if (!(ref & kLeafFlag)) sn[k + c] = u2f(ref + base); }
+            out->nodes.insert(out->nodes.end(), sn.begin(), sn.end());
+            if (frontier[j].parent != kNoParent) set_child(out->nodes, frontier[j].parent, frontier[j].side, base, range_box(frontier[j].begin, frontier[j].end));
+            if (subs[j].depth > out->depth) out->depth = subs[j].depth;
+            std::vector<float>().swap(sn);
         }
     }
     out->n_nodes = (uint32_t)(out->nodes.size() / 16);

@@ -350,6 +350,7 @@ template <bool MOVING> PT_DEV int32_t search_spheres_strict(const SceneView& s, 
 // so the result is the exact closest hit (smallest t > kMinT, lowest original index on an exact tie) whatever the
 // tree looks like -- the same definition the LDS search implements.
 constexpr uint32_t kBvhLeafFlag = 0x80000000u;
+constexpr float kCullSlack = 1.002f;         // box culling distance = closest t so far x this (see bvh_closest)
 constexpr uint32_t kBvhDone = 0xFFFFFFFFu;   // stack sentinel: "nothing left" (a real leaf reference has first < 2^28, so it is never all ones)
 constexpr uint32_t kBvhStack = 64; // deepest tree the traversal accepts (the per-lane LDS stack holds depth + 1 entries; host checks)
 struct BvhView
@@ -406,6 +407,11 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
     unsigned long long qs0 = 0, qs1 = 0, qs2 = 0;
 #endif
     float best = tLimit;               // a plane hit found earlier wins ties against spheres (main.cpp:204)
+    // Boxes are culled against `cull`, not `best`: the reference's sphere formula (geometry.cpp:45-66) forms b*b - 4c,
+    // which cancels down from |o-c|^2 -- its t is off the geometric one by up to ~sqrt(45 * 2^-24) * |o-c| = 8e-4 |o-c|
+    // (0.25 units a thousand units out).  A brute-force search in that arithmetic -- the definition of the query -- can
+    // therefore prefer a sphere that is geometrically just BEHIND the current best; its box must not be culled.
+    float cull = best * kCullSlack;
     int32_t bestSlot = -1;
     // finite reciprocals: a zero direction component must not turn (lo - o) * inv into NaN
     const float big = 1.0e18f;
@@ -445,8 +451,8 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
                 const float4 n0 = b.nodes[4 * cur], n1 = b.nodes[4 * cur + 1], n2 = b.nodes[4 * cur + 2], n3 = b.nodes[4 * cur + 3];
                 // left box {n0.xyz .. n0.w, n1.x, n1.y}, right box {n1.z, n1.w, n2.x .. n2.yzw}
                 float nearL, nearR;
-                const bool hitL = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, best, &nearL);
-                const bool hitR = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, best, &nearR);
+                const bool hitL = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, cull, &nearL);
+                const bool hitR = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, cull, &nearR);
                 const uint32_t refL = __float_as_uint(n3.x), refR = __float_as_uint(n3.y);
                 if (hitL && hitR)
                 {
@@ -493,7 +499,7 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
                         bool take = t < best;
                         if (!take && bestSlot >= 0)
                             take = __float_as_uint(b.mat[2 * slot].w) < __float_as_uint(b.mat[2 * (uint32_t)bestSlot].w);
-                        if (take) { best = t; bestSlot = (int32_t)slot; }
+                        if (take) { best = t; cull = t * kCullSlack; bestSlot = (int32_t)slot; }
                     }
                 }
             }

@@ -51,3 +51,41 @@ def hip_slice_renderer(renderer, width: int, height: int, max_depth: int, seed: 
         return acc
 
     return render_slice
+
+
+def render_progressive(render_slice: Callable[[int, int], "torch.Tensor"], spp_total: int, passes: int,
+                       on_snapshot: Callable[["torch.Tensor", int, int], None] = None, spp_done: int = 0, total: "torch.Tensor" = None,
+                       group=None):
+    """Progressive / resumable accumulation.  The sample range [spp_done, spp_total) is rendered in
+    `passes` contiguous pieces; each piece is split across the ranks like a frame (spp_slice) and all-reduced, then added
+    to the running per-pixel sum.  After every piece rank 0 calls on_snapshot(running_sum, samples_so_far, pass_index) --
+    resolve / write a preview there.  Because the RNG is keyed by the GLOBAL sample index, the union of the pieces is
+    exactly the sample set of a one-shot frame, and a render can be resumed later from (running sum, samples so far):
+    pass them back as `total` and `spp_done`.  Returns (running_sum, spp_total) on rank 0 and (None, spp_total) elsewhere;
+    the reference's only analogue is its progress printout (src/main.cpp:321-332)."""
+    import torch
+    import torch.distributed as dist
+    if passes < 1 or spp_total < spp_done:
+        raise ValueError("bad passes / sample range")
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    todo = spp_total - spp_done
+    done = spp_done
+    for k in range(passes):
+        lo = spp_done + todo * k // passes
+        hi = spp_done + todo * (k + 1) // passes
+        if hi == lo:
+            continue
+        b, e = spp_slice(rank, world, hi - lo)
+        if e > b:
+            acc = render_slice(lo + b, lo + e)
+        else:
+            acc = torch.zeros_like(render_slice(lo, lo + 1))
+        if world > 1:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+        done = hi
+        if rank == 0:
+            total = acc.clone() if total is None else total.add_(acc)
+            if on_snapshot:
+                on_snapshot(total, done, k)
+    return (total if rank == 0 else None), done

@@ -266,3 +266,19 @@ def test_command_line_renderer_matches_the_library(renderer, tmp_path):
     assert out2.read_bytes() == expect
     bad = subprocess.run([exe, "--spp", "0"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 2
+
+
+def test_progressive_accumulation_on_device(renderer):
+    """render_progressive over the real renderer (one rank): pieces of the sample range add up to the one-shot frame."""
+    torch = pytest.importorskip("torch")
+    from pathtracer_amd.distributed import render_progressive, hip_slice_renderer
+    w, h, spp, depth = 64, 36, 24, 10
+    renderer.upload(pt.Scene.builtin(1, w / h))
+    one_shot = renderer.render(w, h, 0, spp, depth, seed=4)
+    seen = []
+    total, done = render_progressive(hip_slice_renderer(renderer, w, h, depth, seed=4), spp, 4, on_snapshot=lambda t, n, k: seen.append(n))
+    torch.cuda.synchronize()
+    assert done == spp and seen == [6, 12, 18, 24]
+    got = total.cpu().numpy()
+    assert _close_sums(got, one_shot, spp)
+    assert np.allclose(got[..., 3], spp, rtol=1e-6)

@@ -89,8 +89,12 @@ def main():
         sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # PT_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, all-reduce, barrier) with a single rank too -- a
+    # rehearsal of the N > 1 plumbing on a one-GPU box; the numbers of such a run are N = 1 numbers.
+    use_dist = world > 1 or os.environ.get("PT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     w, h, S, depth = args.width, args.height, args.spp_per_gpu, args.depth
@@ -108,13 +112,13 @@ def main():
         r.render_device(params, accum.data_ptr(), stream.cuda_stream)
         if ev:
             ev[1].record(stream)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(accum, op=dist.ReduceOp.SUM)  # float accumulation buffer over xGMI, before tonemapping
         if rank == 0:
             r.resolve_device(accum.data_ptr(), w * h, S * world, 0, bgra.data_ptr(), stream.cuda_stream)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -130,7 +134,7 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
     st = r.stats()  # last launch: samples, segments (S-bar), library's own HIP-event time
 
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -191,7 +195,7 @@ def main():
         assert host_img is not None and host_img.shape == (h, w)
         print(json.dumps(out))
     r.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

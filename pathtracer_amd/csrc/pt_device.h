@@ -383,6 +383,36 @@ PT_DEV bool box_hit(float lox, float loy, float loz, float hix, float hiy, float
     *tnear = tn;
     return tf >= fmaxf(tn, 0.0f) && tn <= best;
 }
+// The same test for a CONE around the ray (half-angle kConeEps): the box grown by kConeEps * t at distance t.  Per axis
+//     o + d t - eps t <= hi   and   o + d t + eps t >= lo,
+// i.e. the usual slab test with one reciprocal per PLANE: r1 = 1/(d - eps) for hi, r2 = 1/(d + eps) for lo (folded per
+// ray together with -o r1, -o r2).  Same instruction count per box as box_hit.  |d| <= eps (the cone outgrows the axis):
+// d - eps < 0 < d + eps, both inequalities bound t from BELOW and nothing from above (a side branch, ~3e-3 of rays).
+// Used where the reference's sphere formula works far from its origin (trees in HBM = big scenes): there it reports
+// hits on spheres the ray misses by up to sqrt(45 * 2^-24) / 2 * |o-c| = 8.2e-4 |o-c| (cancellation in b*b - 4c), and a
+// brute-force search in that arithmetic -- the definition of the query -- finds them; the cone makes the tree visit them.
+constexpr float kConeEps = 1.0e-3f;
+PT_DEV bool cone_flat(float d) { return !(fabsf(d) > kConeEps * 1.001f); } // the cone outgrows this axis
+PT_DEV bool box_hit_cone(float lox, float loy, float loz, float hix, float hiy, float hiz, float r1x, float r1y, float r1z, float n1x, float n1y, float n1z,
+                         float r2x, float r2y, float r2z, float n2x, float n2y, float n2z, bool anyFlat, V3 d, float best, float* tnear)
+{
+#pragma clang fp contract(fast)
+    const float a0 = lox * r2x + n2x, a1 = hix * r1x + n1x;
+    const float b0 = loy * r2y + n2y, b1 = hiy * r1y + n1y;
+    const float c0 = loz * r2z + n2z, c1 = hiz * r1z + n1z;
+    float nx = fminf(a0, a1), ny = fminf(b0, b1), nz = fminf(c0, c1);
+    float fx = fmaxf(a0, a1), fy = fmaxf(b0, b1), fz = fmaxf(c0, c1);
+    if (anyFlat) // ~1e-3 of rays per axis: both planes bound t from below, nothing bounds it from above
+    {
+        if (cone_flat(d.x)) { nx = fx; fx = kF32Max; }
+        if (cone_flat(d.y)) { ny = fy; fy = kF32Max; }
+        if (cone_flat(d.z)) { nz = fz; fz = kF32Max; }
+    }
+    const float tn = fmaxf(fmaxf(nx, ny), nz);
+    const float tf = fminf(fminf(fx, fy), fz);
+    *tnear = tn;
+    return tf >= fmaxf(tn, 0.0f) && tn <= best;
+}
 
 struct QueryCtx // per-lane scratch and counters of the sphere query
 {
@@ -398,7 +428,7 @@ struct QueryCtx // per-lane scratch and counters of the sphere query
 #define PT_QSTAMP(var) do { } while (0)
 #endif
 
-template <bool MOVING>
+template <bool MOVING, bool CONE>
 PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float tLimit, bool live, QueryCtx& q, float* tOut, V3* centreOut)
 {
     uint32_t* const stack = q.stack;   // this lane's column, stride 64
@@ -416,12 +446,28 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
     // finite reciprocals: a zero direction component must not turn (lo - o) * inv into NaN
     const float big = 1.0e18f;
     // (v_rcp_f32, 1 ulp: the same relative error on both planes of an axis, far inside the builder's padding)
-    const float ix = fabsf(ray.d.x) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.x) : (ray.d.x < 0 ? -big : big);
-    const float iy = fabsf(ray.d.y) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.y) : (ray.d.y < 0 ? -big : big);
-    const float iz = fabsf(ray.d.z) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.z) : (ray.d.z < 0 ? -big : big);
+    float ix = fabsf(ray.d.x) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.x) : (ray.d.x < 0 ? -big : big);
+    float iy = fabsf(ray.d.y) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.y) : (ray.d.y < 0 ? -big : big);
+    float iz = fabsf(ray.d.z) > 1e-18f ? __builtin_amdgcn_rcpf(ray.d.z) : (ray.d.z < 0 ? -big : big);
     // The slab test as lo*inv + (-o*inv): one fma per plane.  Its rounding error, mapped back to position space, is a
     // few ulp of max(|o|, |lo|) -- the builder pads every box by 16 ulp of the scene extent (camera included).
-    const float nox = -ray.o.x * ix, noy = -ray.o.y * iy, noz = -ray.o.z * iz;
+    float nox = -ray.o.x * ix, noy = -ray.o.y * iy, noz = -ray.o.z * iz;
+    // cone form (box_hit_cone): (ix, nox) become the hi-plane pair (r1, n1), (r2, n2) is the lo-plane pair
+    float r2x = 0, r2y = 0, r2z = 0, n2x = 0, n2y = 0, n2z = 0;
+    if (CONE)
+    {
+        auto cone_axis = [](float o, float d, float& r1, float& n1, float& r2, float& n2)
+        {
+            // (on a flat axis d - eps and d + eps straddle zero; keep both away from it so the reciprocals stay finite)
+            const bool flat = cone_flat(d);
+            const float s1 = flat ? fminf(d - kConeEps, -kConeEps * 1.0e-3f) : d - kConeEps;
+            const float s2 = flat ? fmaxf(d + kConeEps, kConeEps * 1.0e-3f) : d + kConeEps;
+            r1 = __builtin_amdgcn_rcpf(s1); n1 = -o * r1;
+            r2 = __builtin_amdgcn_rcpf(s2); n2 = -o * r2;
+        };
+        cone_axis(ray.o.x, ray.d.x, ix, nox, r2x, n2x); cone_axis(ray.o.y, ray.d.y, iy, noy, r2y, n2y); cone_axis(ray.o.z, ray.d.z, iz, noz, r2z, n2z);
+    }
+    const bool anyFlat = CONE && (cone_flat(ray.d.x) || cone_flat(ray.d.y) || cone_flat(ray.d.z));
     // The stack pointer is the LDS address itself (this lane's column, 64 dwords per level); level 0 holds a sentinel,
     // so "pop" needs no emptiness test: popping the sentinel ends the lane's traversal.
     uint32_t* sp = stack;
@@ -451,8 +497,10 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
                 const float4 n0 = b.nodes[4 * cur], n1 = b.nodes[4 * cur + 1], n2 = b.nodes[4 * cur + 2], n3 = b.nodes[4 * cur + 3];
                 // left box {n0.xyz .. n0.w, n1.x, n1.y}, right box {n1.z, n1.w, n2.x .. n2.yzw}
                 float nearL, nearR;
-                const bool hitL = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, cull, &nearL);
-                const bool hitR = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, cull, &nearR);
+                const bool hitL = CONE ? box_hit_cone(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearL)
+                                       : box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, cull, &nearL);
+                const bool hitR = CONE ? box_hit_cone(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearR)
+                                       : box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, cull, &nearR);
                 const uint32_t refL = __float_as_uint(n3.x), refR = __float_as_uint(n3.y);
                 if (hitL && hitR)
                 {
@@ -549,7 +597,7 @@ template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, cons
     uint32_t origIndex = 0;
     if (MODE == MODE_BVH || MODE == MODE_BVH_LDS)
     {
-        obj = bvh_closest<MOVING>(q.bvh, ray, time, h.t, live, q, &t, &centre);
+        obj = bvh_closest<MOVING, MODE == MODE_BVH>(q.bvh, ray, time, h.t, live, q, &t, &centre);
         if (obj >= 0) { sphereMat = load_material(q.bvh.mat, (uint32_t)obj); origIndex = __float_as_uint(q.bvh.mat[2 * (uint32_t)obj].w); }
     }
     else if (STRICT)

@@ -111,13 +111,15 @@ def test_lds_and_bvh_paths_agree(renderer, oracle):
     assert e.value.status == pt.PT_ERR_UNSUPPORTED
 
 
-def test_large_scene_matches_up_to_the_reference_formulas_cancellation(renderer, oracle):
+def test_large_scene_reproduces_the_reference_formulas_phantom_hits(renderer, oracle):
     """100 000 spheres over a 1000-unit slab (C5 geometry; >= 65 536 spheres also exercises the multi-threaded builder).
     Out there the reference's own sphere formula (geometry.cpp:45-66) stops agreeing with geometry: b*b - 4c cancels down
     from |o-c|^2 ~ 3e5, so its discriminant carries an error of ~45 * 2^-24 * |o-c|^2 ~ 0.1-0.7 and it reports PHANTOM hits
-    on spheres the ray misses by a tenth of a unit.  A brute-force search in that arithmetic (the oracle) collects them; a
-    tree is entered only where the ray really passes, so it does not.  The bar here: every record agrees bit for bit
-    EXCEPT where the oracle's winner is such a phantom (verified in f64), and those are < 1e-3 of the rays."""
+    on spheres the ray misses by a tenth of a unit.  A brute-force search in that arithmetic (the oracle, = the definition
+    of the query) collects them.  The tree-in-HBM kernel therefore tests boxes against a CONE around the ray (half-angle
+    1e-3 >= the formula's worst case 8.2e-4) and culls against 1.002 x the closest t; with plain boxes 2e-4 of these
+    rays differed.  The bar: bit-equal records; should a difference ever appear it must at least be one the formula's
+    cancellation explains (checked in f64 below), never a traversal error."""
     sa = builtin_scene_arrays(5, 16 / 9, 100000)
     renderer.upload(to_pt_scene(sa))
     h = oracle.scene(sa)
@@ -132,7 +134,8 @@ def test_large_scene_matches_up_to_the_reference_formulas_cancellation(renderer,
     same = prim == po_
     assert bit_equal(t[same], to[same]) and bit_equal(p[same], pto[same]) and bit_equal(nr[same], nro[same])
     bad = np.nonzero(~same)[0]
-    assert len(bad) <= 1e-3 * n, len(bad)
+    print(f"large scene: {len(bad)} of {n} records differ from the brute-force oracle")
+    assert len(bad) <= 1e-4 * n, len(bad)
 
     def conditioning(i, sphere):           # (f64 quarter discriminant, error bound of the f32 formula) for ray i
         c = sa.pos_r[sphere].astype(np.float64)

@@ -49,12 +49,14 @@ inline float aabb_area(const Aabb& b)
 inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-constexpr uint32_t kLeafMax = 4;
+constexpr uint32_t kLeafMaxDefault = 4; // spheres per leaf (<= 8: three bits of the leaf reference)
 constexpr uint32_t kLeafFlag = 0x80000000u;
 
 inline void build_bvh(const pt_scene_desc* d, BvhData* out)
 {
     const uint32_t n = d->n_spheres;
+    uint32_t kLeafMax = kLeafMaxDefault;
+    if (const char* e = getenv("PT_LEAF_MAX")) { int v = atoi(e); if (v >= 1 && v <= 8) kLeafMax = (uint32_t)v; } // tuning experiments only
     out->n_spheres = n;
     out->moving = false;
     if (d->sphere_vel)

@@ -1,10 +1,13 @@
 // pt_hip.hip -- kernels and C-ABI of libpt_hip.so (gfx950 only; see include/pt_hip.h for the boundary).
 //
 // Kernels
-//   k_render<MOVING,STRICT>  the hot path: one wave = one 8x8 pixel tile x all samples of the call; lanes pull
-//                                (pixel, sample) work items from a wave-local pool so that a lane whose path ended
-//                                starts its next sample in the same iteration (path regeneration); the scene is
-//                                staged once per workgroup into LDS and searched by brute force.
+//   k_render{,_w6,_w7}<MOVING,MODE>  the hot path (one body, three register budgets).  Persistent waves pull work units
+//                                -- (8x8 pixel tile, sample chunk) -- from a global cursor; inside a unit the lanes pull
+//                                (pixel, sample) items from a wave-local pool, so a lane whose path ended starts its
+//                                next sample in the same trip (path regeneration).  MODE picks the sphere query: own BVH
+//                                staged in LDS (default) or read from HBM (big scenes), packed brute force over the
+//                                LDS-resident scene, or the strict linear search (tests).
+//   k_fold_chunks                adds the per-chunk partial images in chunk order.
 //   k_probe_*                    the same device functions on caller-supplied records (parity harness).
 //   k_resolve                    clamp(mean) + gamma-2 + 8-bit BGRA pack.
 // Host code below the kernels implements include/pt_hip.h.
@@ -40,8 +43,8 @@ struct SceneArgs
     uint32_t leaf_batch;    // lanes that must wait at a leaf before the wave runs the leaf code (BVH modes)
 };
 
-// LDS carve-up behind the blob: per wave, [64 pixels x rgba] accumulators (render kernel) and, in MODE_BVH, a
-// 32 x 64 traversal stack.
+// LDS carve-up behind the scene image: per wave, [64 pixels x rgba] accumulators (render kernel) and, in the BVH modes,
+// a (tree depth + 1) x 64 traversal stack.
 template <int MODE> __device__ __forceinline__ QueryCtx make_query(const SceneArgs& a, const float4* smem, uint32_t* stackBase)
 {
     QueryCtx q;
@@ -99,7 +102,7 @@ __host__ __device__ inline uint32_t chunk_size(uint32_t remaining, uint32_t rati
 }
 
 constexpr uint32_t kWavesPerBlock = 4;     // LDS modes: four waves share one staged copy of the scene
-constexpr uint32_t kWavesPerBlockBvh = 1;  // BVH mode: one wave per workgroup, so that LDS (8 KB of stack per wave) packs tightly
+constexpr uint32_t kWavesPerBlockBvh = 1;  // tree in HBM: nothing to share, one wave per workgroup packs best
 
 // ================================================================================================ the hot kernel
 template <bool MOVING, int MODE>

@@ -282,3 +282,31 @@ def test_progressive_accumulation_on_device(renderer):
     got = total.cpu().numpy()
     assert _close_sums(got, one_shot, spp)
     assert np.allclose(got[..., 3], spp, rtol=1e-6)
+
+
+@pytest.mark.parametrize("name,sid,w,h,spp,depth", [
+    ("C2_materials_dof_1080p", 4, 1920, 1080, 16, 50),      # BASELINE.json config 2 geometry: metal + glass + lens
+    ("C4_motion_blur_4k", 3, 3840, 2160, 16, 50),           # BASELINE.json config 4 geometry: moving spheres, 4K
+])
+def test_full_size_properties_other_configs(renderer, oracle, name, sid, w, h, spp, depth):
+    """Full-size frames of the other BASELINE.json configurations: every sample lands exactly once (alpha), radiance is
+    bounded, the frame is linear in the sample range, and a strided subset of samples is bit-equal to the oracle."""
+    sa = builtin_scene_arrays(sid, w / h)
+    renderer.upload(to_pt_scene(sa))
+    img = renderer.render(w, h, 0, spp, depth, seed=2)
+    st = renderer.stats()
+    assert st["samples"] == w * h * spp
+    assert np.isfinite(img).all() and (img >= 0).all()
+    assert np.allclose(img[..., 3], spp, rtol=1e-6)
+    assert (img[..., :3] <= spp * 1.0000001).all()
+    parts = renderer.render(w, h, 0, 5, depth, seed=2) + renderer.render(w, h, 5, spp, depth, seed=2)
+    assert np.abs(img - parts).max() <= 2 * spp * 2.0 ** -24 * spp
+    ys, xs = np.meshgrid(np.arange(7, h, 211), np.arange(5, w, 307), indexing="ij")
+    pix = (ys * w + xs).reshape(-1).astype(np.uint32)
+    oh = oracle.scene(sa)
+    for s in (0, spp - 1):
+        smp = np.full(len(pix), s, np.uint32)
+        c, segs = renderer.probe_samples(w, h, pix, smp, depth, seed=2)
+        co, segso = oracle.samples_philox(oh, w, h, pix, smp, depth, seed=2)
+        assert (segs == segso).all() and bit_equal(c, co), (name, s)
+    oracle.scene_free(oh)

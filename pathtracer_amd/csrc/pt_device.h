@@ -122,6 +122,11 @@ template <class R> PT_DEV float rand_range(R& r, float lo, float hi) { return r.
 
 // ------------------------------------------------------------------ samplers (utils.h:71-138)
 // Draw order z,y,x / y,x: what g++ makes of the reference's unspecified argument order.
+// The reference accepts a point when norm(p) <= 1 with norm = sqrt(x*x + y*y + z*z).  For a correctly rounded square
+// root, sqrt(s) <= 1 holds exactly when s <= 1 + 2^-23 (sqrt(1 + 2^-23) = 1 + 2^-24 - ... rounds down to 1, sqrt of the
+// next float does not; sqrt is monotone; NaN fails both) -- the same decisions without the ~15-instruction exact root
+// in each trip of the two rejection loops.
+constexpr float kOnePlusUlp = 1.00000011920928955078125f; // 0x3F800001
 template <class R> PT_DEV V3 random_point_in_unit_sphere(R& r)               // utils.h:80-94
 {
     V3 p;
@@ -129,7 +134,7 @@ template <class R> PT_DEV V3 random_point_in_unit_sphere(R& r)               // 
     {
         float z = rand_range(r, -1.0f, 1.0f), y = rand_range(r, -1.0f, 1.0f), x = rand_range(r, -1.0f, 1.0f);
         p = v3(x, y, z);
-        if (norm(p) <= 1.0f) break;
+        if (norm_squared(p) <= kOnePlusUlp) break;                       // == (norm(p) <= 1.0f), see above
     }
     return p;
 }
@@ -141,7 +146,7 @@ template <class R> PT_DEV V3 random_point_in_unit_circle(R& r)               // 
     {
         float y = rand_range(r, -1.0f, 1.0f), x = rand_range(r, -1.0f, 1.0f);
         p = v3(x, y, 0.0f);
-        if (norm(p) <= 1.0f) break;
+        if (norm_squared(p) <= kOnePlusUlp) break;                       // == (norm(p) <= 1.0f), see above
     }
     return p;
 }

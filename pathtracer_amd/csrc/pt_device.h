@@ -33,6 +33,9 @@ PT_DEV V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }   // v
 PT_DEV V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }   // vectors.cpp:22-29
 PT_DEV V3 mul(V3 v, float s) { return v3(v.x * s, v.y * s, v.z * s); }      // vectors.cpp:31-42
 PT_DEV V3 neg(V3 v) { return v3(-v.x, -v.y, -v.z); }                        // vectors.cpp:49-56
+// Lane mask of a predicate.  (HIP's __ballot(int) widens the bool and compares it with zero again -- a v_cndmask and a
+// v_cmp per call that the compiler does not fold; the builtin takes the i1 as it is.)
+PT_DEV unsigned long long pt_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 PT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   // vectors.cpp:132-135
 PT_DEV float norm_squared(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; } // vectors.cpp:112-115
 PT_DEV float norm(V3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); } // vectors.cpp:107-110 (correctly rounded sqrt)
@@ -286,7 +289,7 @@ template <bool MOVING, bool WIDE> PT_DEV int32_t search_spheres_fast(const Scene
             const bool t1 = live && ds0.y > 0.0f && !(hb0.y > 0.0f && cc0.y > 0.0f);
             const bool t2 = live && ds1.x > 0.0f && !(hb1.x > 0.0f && cc1.x > 0.0f);
             const bool t3 = live && ds1.y > 0.0f && !(hb1.y > 0.0f && cc1.y > 0.0f);
-            todo = (__ballot(t0) ? 1u : 0u) | (__ballot(t1) ? 2u : 0u) | (__ballot(t2) ? 4u : 0u) | (__ballot(t3) ? 8u : 0u);
+            todo = (pt_ballot(t0) ? 1u : 0u) | (pt_ballot(t1) ? 2u : 0u) | (pt_ballot(t2) ? 4u : 0u) | (pt_ballot(t3) ? 8u : 0u);
         }
         while (todo) // wave-uniform
         {
@@ -490,8 +493,8 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
         for (;;)
         {
             const bool atInner = !(cur & kBvhLeafFlag);                  // (the sentinel carries the leaf flag)
-            const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner));
-            const uint32_t nLeaf = (uint32_t)__popcll(__ballot(!atInner && cur != kBvhDone));
+            const uint32_t nInner = (uint32_t)__popcll(pt_ballot(atInner));
+            const uint32_t nLeaf = (uint32_t)__popcll(pt_ballot(!atInner && cur != kBvhDone));
             if (nInner == 0u || nLeaf >= leafBatch) break;
 #ifdef PT_STAMPS
             ++q.innerIters;
@@ -522,7 +525,7 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
 #ifdef PT_STAMPS
         q.cycInner += qs1 - qs0;
 #endif
-        if (__ballot(cur != kBvhDone) == 0ull) break;
+        if (pt_ballot(cur != kBvhDone) == 0ull) break;
 #ifdef PT_STAMPS
         ++q.leafIters;
 #endif
@@ -531,7 +534,7 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
         const uint32_t first = cur & 0x0FFFFFFFu, count = atLeaf ? ((cur >> 28) & 7u) + 1u : 0u;
         for (uint32_t k = 0;; ++k)
         {
-            const unsigned long long todo = __ballot(k < count);
+            const unsigned long long todo = pt_ballot(k < count);
             if (todo == 0ull) break;
             q.sphereTests += (uint32_t)__popcll(todo);                   // wave-level tally
             if (k < count)

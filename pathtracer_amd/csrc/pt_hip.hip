@@ -164,7 +164,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
         PT_STAMP(ts0);
         // ---- refill: every lane without a live path takes the next work item (main.cpp:347-354)
         const bool want = !alive && !retired;
-        const unsigned long long need = __ballot(want);
+        const unsigned long long need = pt_ballot(want);
         if (need)
         {
             if (want)
@@ -191,7 +191,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
             }
             next += (uint32_t)__popcll(need);
         }
-        if (__ballot(alive) == 0ull)
+        if (pt_ballot(alive) == 0ull)
         {
             if (next >= total) break;
             continue;

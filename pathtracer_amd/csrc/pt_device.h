@@ -436,21 +436,45 @@ struct QueryCtx // per-lane scratch and counters of the sphere query
 #define PT_QSTAMP(var) do { } while (0)
 #endif
 
-template <bool MOVING, bool CONE>
-PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float tLimit, bool live, QueryCtx& q, float* tOut, V3* centreOut)
+// The traversal of one lane between calls of bvh_run: where it stands (node / leaf reference, or kBvhDone), its stack
+// pointer (the stack itself lives in LDS), the closest hit so far.  A query is trav_begin -> bvh_run (once, or several
+// times when the run is left early) -> the hit record.
+// (pk = stack level | (index of the closest plane + 1) << 8: the state is live across the shading of other lanes, where
+// registers are short.  Parking it in LDS instead was tried: three more stack entries per lane cost the seventh
+// workgroup of a CU.)
+struct TravState { uint32_t cur; float best; int32_t bestSlot; uint32_t pk; };
+PT_DEV int32_t trav_plane(uint32_t pk) { return (int32_t)(pk >> 8) - 1; }
+PT_DEV void trav_begin(const BvhView& b, float tLimit, int32_t planeIdx, bool live, const QueryCtx& q, TravState& ts)
 {
-    uint32_t* const stack = q.stack;   // this lane's column, stride 64
+    ts.best = tLimit;                  // a plane hit found earlier wins ties against spheres (main.cpp:204)
+    ts.bestSlot = -1;
+    // The stack pointer is the LDS address itself (this lane's column, 64 dwords per level); level 0 holds a sentinel,
+    // so "pop" needs no emptiness test: popping the sentinel ends the lane's traversal.
+    ts.pk = (uint32_t)(planeIdx + 1) << 8;
+    *q.stack = kBvhDone;
+    // A lane without a live path holds a stale ray: it starts on the sentinel, so it cannot keep the wave in the loop.
+    ts.cur = (live && b.n_spheres != 0) ? b.root_ref : kBvhDone;
+}
+
+// Advances the traversals of the wave.  minActive = 0: until every lane is done.  minActive > 0: the run is also left
+// as soon as fewer than minActive lanes are still traversing AND more live lanes than that have finished -- the
+// stragglers keep their state (ts, LDS stack) and carry on in the next call, together with the rays the finished lanes
+// will have produced by then.  (Measured on book-1: 33 % of the inner steps and 44 % of the leaf steps of a
+// run-to-completion traversal are executed for fewer than 8 lanes.)
+template <bool MOVING, bool CONE>
+PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, QueryCtx& q, TravState& ts, uint32_t minActive)
+{
     const uint32_t leafBatch = q.leafBatch;
 #ifdef PT_STAMPS
     unsigned long long qs0 = 0, qs1 = 0, qs2 = 0;
 #endif
-    float best = tLimit;               // a plane hit found earlier wins ties against spheres (main.cpp:204)
+    float best = ts.best;
     // Boxes are culled against `cull`, not `best`: the reference's sphere formula (geometry.cpp:45-66) forms b*b - 4c,
     // which cancels down from |o-c|^2 -- its t is off the geometric one by up to ~sqrt(45 * 2^-24) * |o-c| = 8e-4 |o-c|
     // (0.25 units a thousand units out).  A brute-force search in that arithmetic -- the definition of the query -- can
     // therefore prefer a sphere that is geometrically just BEHIND the current best; its box must not be culled.
     float cull = best * kCullSlack;
-    int32_t bestSlot = -1;
+    int32_t bestSlot = ts.bestSlot;
     // finite reciprocals: a zero direction component must not turn (lo - o) * inv into NaN
     const float big = 1.0e18f;
     // (v_rcp_f32, 1 ulp: the same relative error on both planes of an axis, far inside the builder's padding)
@@ -476,13 +500,10 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
         cone_axis(ray.o.x, ray.d.x, ix, nox, r2x, n2x); cone_axis(ray.o.y, ray.d.y, iy, noy, r2y, n2y); cone_axis(ray.o.z, ray.d.z, iz, noz, r2z, n2z);
     }
     const bool anyFlat = CONE && (cone_flat(ray.d.x) || cone_flat(ray.d.y) || cone_flat(ray.d.z));
-    // The stack pointer is the LDS address itself (this lane's column, 64 dwords per level); level 0 holds a sentinel,
-    // so "pop" needs no emptiness test: popping the sentinel ends the lane's traversal.
-    uint32_t* sp = stack;
-    *sp = kBvhDone;
-    // A lane without a live path holds a stale ray: it starts on the sentinel, so it cannot keep the wave in the loop.
     // All lanes run the loops below together (their exits are wave-uniform), which keeps the two tallies in scalar registers.
-    uint32_t cur = (live && b.n_spheres != 0) ? b.root_ref : kBvhDone;
+    uint32_t* sp = q.stack + (ts.pk & 255u) * 64u;
+    uint32_t cur = ts.cur;
+    bool leave = false;
     // Two kinds of step, and a wave pays for both whenever its lanes disagree.  Leaf steps are the dear ones (up to
     // four sphere tests, the exact evaluation among them), so lanes that reach a leaf WAIT there while the others keep
     // descending; the leaf code runs once enough lanes have gathered (or nobody is left on an inner node).
@@ -496,6 +517,7 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
             const uint32_t nInner = (uint32_t)__popcll(pt_ballot(atInner));
             const uint32_t nLeaf = (uint32_t)__popcll(pt_ballot(!atInner && cur != kBvhDone));
             if (nInner == 0u || nLeaf >= leafBatch) break;
+            if (nInner + nLeaf < minActive && (uint32_t)__popcll(pt_ballot(live && cur == kBvhDone)) > nInner + nLeaf) { leave = true; break; }
 #ifdef PT_STAMPS
             ++q.innerIters;
 #endif
@@ -525,7 +547,12 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
 #ifdef PT_STAMPS
         q.cycInner += qs1 - qs0;
 #endif
-        if (pt_ballot(cur != kBvhDone) == 0ull) break;
+        if (leave) break;
+        {
+            const unsigned long long act = pt_ballot(cur != kBvhDone);
+            if (act == 0ull) break;
+            if ((uint32_t)__popcll(act) < minActive && (uint32_t)__popcll(pt_ballot(live && cur == kBvhDone)) > (uint32_t)__popcll(act)) break;
+        }
 #ifdef PT_STAMPS
         ++q.leafIters;
 #endif
@@ -566,16 +593,20 @@ PT_DEV int32_t bvh_closest(const BvhView& b, const Ray& ray, float time, float t
         q.cycLeaf += qs2 - qs1;
 #endif
     }
-    *tOut = best;
+    ts.cur = cur; ts.best = best; ts.bestSlot = bestSlot;
+    ts.pk = (ts.pk & ~255u) | ((uint32_t)(sp - q.stack) >> 6);
+}
+// The winner's centre, as the leaf test saw it.
+template <bool MOVING> PT_DEV V3 trav_centre(const BvhView& b, int32_t slot, float time)
+{
     V3 centre = v3(0, 0, 0);
-    if (bestSlot >= 0)                 // the winner's centre, as the leaf test saw it
+    if (slot >= 0)
     {
-        const float4 sd = b.sph[(uint32_t)bestSlot];
+        const float4 sd = b.sph[(uint32_t)slot];
         centre = v3(sd.x, sd.y, sd.z);
-        if (MOVING) { const float4 vd = b.vel[(uint32_t)bestSlot]; centre = add(centre, mul(v3(vd.x, vd.y, vd.z), time)); }
+        if (MOVING) { const float4 vd = b.vel[(uint32_t)slot]; centre = add(centre, mul(v3(vd.x, vd.y, vd.z), time)); }
     }
-    *centreOut = centre;
-    return bestSlot;
+    return centre;
 }
 
 struct Hit { float t; int32_t prim; V3 point, normal; Material m; };
@@ -584,31 +615,74 @@ struct Hit { float t; int32_t prim; V3 point, normal; Material m; };
 enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2, MODE_BVH_LDS = 3 }; // BVH: tree in HBM; BVH_LDS: tree staged in LDS
 
 // First half of cast_ray (main.cpp:180-216): planes linearly, then the sphere query; closest wins, planes win ties.
+// plane loop (main.cpp:186-200): closest plane hit, or kF32Max / -1
+PT_DEV float closest_plane(const SceneView& s, const Ray& ray, int32_t* planeIdxOut)
+{
+    float tBest = kF32Max;
+    int32_t planeIdx = -1;
+    for (uint32_t i = 0; i < s.np; ++i)
+    {
+        float4 p = s.planes[i];
+        float t = intersect_plane_exact(ray, v3(p.x, p.y, p.z), p.w);
+        if (t > kMinT && t < tBest) { tBest = t; planeIdx = (int32_t)i; }
+    }
+    *planeIdxOut = planeIdx;
+    return tBest;
+}
+// the hit record (main.cpp:204-216) from the winners of the two searches: sphere `obj` at t (-1: none) and plane planeIdx at planeT
+PT_DEV Hit make_hit(const SceneView& s, const Ray& ray, int32_t obj, float t, V3 centre, const Material& sphereMat, uint32_t origIndex, int32_t planeIdx, float planeT)
+{
+    Hit h;
+    h.t = planeT; h.prim = kPrimMiss; h.point = v3(0, 0, 0); h.normal = v3(0, 0, 0);
+    h.m.type = MAT_NONE; h.m.colour = v4(0, 0, 0, 0); h.m.roughness = 0; h.m.n = 0;
+    if (obj >= 0 && t > kMinT && t < h.t)
+    {
+        h.t = t; h.prim = (int32_t)origIndex;
+        h.point = ray_at(ray, t);
+        h.normal = normalize(sub(h.point, centre));
+        h.m = sphereMat;
+    }
+    else if (planeIdx >= 0)
+    {
+        float4 p = s.planes[planeIdx];
+        h.prim = -1 - planeIdx;
+        h.point = ray_at(ray, h.t);
+        h.normal = v3(p.x, p.y, p.z);
+        h.m = load_material(s.pmat, (uint32_t)planeIdx);
+    }
+    return h;
+}
+// ... for the BVH kernels: from a finished traversal (best = the plane's t unless a sphere beat it)
+template <bool MOVING> PT_DEV Hit make_hit_bvh(const SceneView& s, const Ray& ray, float time, const QueryCtx& q, const TravState& ts)
+{
+    const int32_t planeIdx = trav_plane(ts.pk);
+    const int32_t obj = ts.bestSlot;
+    Material sphereMat; sphereMat.type = MAT_NONE; sphereMat.colour = v4(0, 0, 0, 0); sphereMat.roughness = 0; sphereMat.n = 0;
+    uint32_t origIndex = 0;
+    if (obj >= 0) { sphereMat = load_material(q.bvh.mat, (uint32_t)obj); origIndex = __float_as_uint(q.bvh.mat[2 * (uint32_t)obj].w); }
+    // a sphere is recorded only when its t is below the plane's (ties stay with the plane), so with obj >= 0 the plane's
+    // t is anything above ts.best, and without it ts.best still is the plane's t
+    return make_hit(s, ray, obj, ts.best, trav_centre<MOVING>(q.bvh, obj, time), sphereMat, origIndex, planeIdx, obj >= 0 ? kF32Max : ts.best);
+}
 template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, const Ray& ray, float time, bool live, QueryCtx& q)
 {
     constexpr bool STRICT = MODE == MODE_LDS_STRICT;
     uint32_t* searched = &q.searched;
-    Hit h;
-    h.t = kF32Max; h.prim = kPrimMiss; h.point = v3(0, 0, 0); h.normal = v3(0, 0, 0);
-    h.m.type = MAT_NONE; h.m.colour = v4(0, 0, 0, 0); h.m.roughness = 0; h.m.n = 0;
     int32_t planeIdx = -1;
-    for (uint32_t i = 0; i < s.np; ++i)                                  // main.cpp:186-200
+    const float planeT = closest_plane(s, ray, &planeIdx);
+    if (MODE == MODE_BVH || MODE == MODE_BVH_LDS)
     {
-        float4 p = s.planes[i];
-        float t = intersect_plane_exact(ray, v3(p.x, p.y, p.z), p.w);
-        if (t > kMinT && t < h.t) { h.t = t; planeIdx = (int32_t)i; }
+        TravState ts;
+        trav_begin(q.bvh, planeT, planeIdx, live, q, ts);
+        bvh_run<MOVING, MODE == MODE_BVH>(q.bvh, ray, time, live, q, ts, 0u);
+        return make_hit_bvh<MOVING>(s, ray, time, q, ts);
     }
     int32_t obj;
     float t = kF32Max;
     V3 centre = v3(0, 0, 0);
     Material sphereMat; sphereMat.type = MAT_NONE; sphereMat.colour = v4(0, 0, 0, 0); sphereMat.roughness = 0; sphereMat.n = 0;
     uint32_t origIndex = 0;
-    if (MODE == MODE_BVH || MODE == MODE_BVH_LDS)
-    {
-        obj = bvh_closest<MOVING, MODE == MODE_BVH>(q.bvh, ray, time, h.t, live, q, &t, &centre);
-        if (obj >= 0) { sphereMat = load_material(q.bvh.mat, (uint32_t)obj); origIndex = __float_as_uint(q.bvh.mat[2 * (uint32_t)obj].w); }
-    }
-    else if (STRICT)
+    if (STRICT)
     {
         obj = search_spheres_strict<MOVING>(s, ray, time, &t);
         if (obj >= 0)
@@ -653,23 +727,8 @@ template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, cons
             }
         }
     }
-    if (MODE != MODE_BVH && MODE != MODE_BVH_LDS && obj >= 0) { sphereMat = load_material(s.smat, (uint32_t)obj); origIndex = original_index(s, (uint32_t)obj); }
-    if (obj >= 0 && t > kMinT && t < h.t)                                // main.cpp:204-216
-    {
-        h.t = t; h.prim = (int32_t)origIndex;
-        h.point = ray_at(ray, t);
-        h.normal = normalize(sub(h.point, centre));
-        h.m = sphereMat;
-    }
-    else if (planeIdx >= 0)
-    {
-        float4 p = s.planes[planeIdx];
-        h.prim = -1 - planeIdx;
-        h.point = ray_at(ray, h.t);
-        h.normal = v3(p.x, p.y, p.z);
-        h.m = load_material(s.pmat, (uint32_t)planeIdx);
-    }
-    return h;
+    if (obj >= 0) { sphereMat = load_material(s.smat, (uint32_t)obj); origIndex = original_index(s, (uint32_t)obj); }
+    return make_hit(s, ray, obj, t, centre, sphereMat, origIndex, planeIdx, planeT);
 }
 
 // reflectance (main.cpp:161-168): the reference's f64 island.  pow(x,5) is evaluated as x*x*x*x*x here; it feeds

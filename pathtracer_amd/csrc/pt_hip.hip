@@ -41,6 +41,7 @@ struct SceneArgs
     uint32_t bvh_off[4]; //   the arrays sit inside the blob at these float4 offsets (nodes, sph, vel, mat)
     uint32_t stack_entries; // per-lane traversal stack capacity carved from LDS (BVH modes)
     uint32_t leaf_batch;    // lanes that must wait at a leaf before the wave runs the leaf code (BVH modes)
+    uint32_t exit_lanes;    // a trip's traversal phase is left once fewer lanes than this still traverse and one is ready to shade
 };
 
 // LDS carve-up behind the scene image: per wave, [64 pixels x rgba] accumulators (render kernel) and, in the BVH modes,
@@ -105,7 +106,7 @@ constexpr uint32_t kWavesPerBlock = 4;     // LDS modes: four waves share one st
 constexpr uint32_t kWavesPerBlockBvh = 1;  // tree in HBM: nothing to share, one wave per workgroup packs best
 
 // ================================================================================================ the hot kernel
-template <bool MOVING, int MODE>
+template <bool MOVING, int MODE, bool RESUME>
 __device__ __forceinline__ void render_body(const RenderArgs& a)
 {
     extern __shared__ float4 smem[];
@@ -158,6 +159,10 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     V4 T = v4(1, 1, 1, 1);
     float time = 0.0f;
     uint32_t depth = 0, p = 0;
+    // BVH kernels: a lane's sphere query may span several trips (bvh_run's early exit); ts.cur != kBvhDone marks a
+    // lane whose query is under way.
+    constexpr bool kBvh = RESUME && (MODE == MODE_BVH || MODE == MODE_BVH_LDS);
+    TravState ts; ts.cur = kBvhDone; ts.best = 0.0f; ts.bestSlot = -1; ts.pk = 0;
 
     for (;;)
     {
@@ -200,9 +205,24 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
         ++iters;
         PT_STAMP(ts1);
         Ray ray; ray.o = v3(rox, roy, roz); ray.d = v3(rdx, rdy, rdz);
-        const Hit h = closest_hit<MOVING, MODE>(s, ray, time, alive, qc);
+        Hit h;
+        bool ready = alive;
+        if constexpr (kBvh)
+        {
+            if (ts.cur == kBvhDone) // a new segment: planes first, then the tree from its root (a lane without a path parks on the sentinel)
+            {
+                int32_t planeIdx = -1;
+                const float planeT = closest_plane(s, ray, &planeIdx);
+                trav_begin(qc.bvh, planeT, planeIdx, alive, qc, ts);
+            }
+            bvh_run<MOVING, MODE == MODE_BVH>(qc.bvh, ray, time, alive, qc, ts, a.sc.exit_lanes);
+            ready = alive && ts.cur == kBvhDone;
+            if (ready) h = make_hit_bvh<MOVING>(s, ray, time, qc, ts);
+        }
+        else
+            h = closest_hit<MOVING, MODE>(s, ray, time, alive, qc);
         PT_STAMP(ts2);
-        if (alive)
+        if (ready)
         {
             ++segs;
             V4 terminal;
@@ -262,25 +282,31 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
 // dependent loads; the measured optimum (book-1 1080p, tools/ab.py) is 7 waves per SIMD (<= 72 VGPRs) for the tree in
 // LDS and 6 (<= 80) for the tree in HBM and for the brute-force search; the strict search is a test oracle and is left
 // to the compiler.
-template <bool MOVING, int MODE> __global__ void __launch_bounds__(512) k_render(RenderArgs a) { render_body<MOVING, MODE>(a); }
+// RESUME: sphere queries that may span trips (bvh_run); scenes with a handful of spheres do without (the carried state
+// costs them 3 %).
+template <bool MOVING, int MODE> __global__ void __launch_bounds__(512) k_render(RenderArgs a) { render_body<MOVING, MODE, false>(a); }
 #ifdef PT_NO_EU
 #define PT_EU(n)
 #else
 #define PT_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
-template <bool MOVING, int MODE> __global__ void __launch_bounds__(512) PT_EU(6) k_render_w6(RenderArgs a) { render_body<MOVING, MODE>(a); }
-template <bool MOVING, int MODE> __global__ void __launch_bounds__(512) PT_EU(7) k_render_w7(RenderArgs a) { render_body<MOVING, MODE>(a); }
+template <bool MOVING, int MODE, bool RESUME> __global__ void __launch_bounds__(512) PT_EU(6) k_render_w6(RenderArgs a) { render_body<MOVING, MODE, RESUME>(a); }
+#ifndef PT_LDS_WAVES
+#define PT_LDS_WAVES 7 // experiments: make variant DEFS=-DPT_LDS_WAVES=6
+#endif
+template <bool MOVING, int MODE, bool RESUME> __global__ void __launch_bounds__(512) PT_EU(PT_LDS_WAVES) k_render_w7(RenderArgs a) { render_body<MOVING, MODE, RESUME>(a); }
 using RenderKernel = void (*)(RenderArgs);
-template <bool MOVING, int MODE> RenderKernel render_kernel_for()
+template <bool MOVING, int MODE> RenderKernel render_kernel_for(bool resume)
 {
-    if constexpr (MODE == MODE_BVH_LDS) return &k_render_w7<MOVING, MODE>;
+    if constexpr (MODE == MODE_BVH_LDS) return resume ? &k_render_w7<MOVING, MODE, true> : &k_render_w7<MOVING, MODE, false>;
+    else if constexpr (MODE == MODE_BVH) return resume ? &k_render_w6<MOVING, MODE, true> : &k_render_w6<MOVING, MODE, false>;
     else if constexpr (MODE == MODE_LDS_STRICT) return &k_render<MOVING, MODE>;
-    else return &k_render_w6<MOVING, MODE>;
+    else return &k_render_w6<MOVING, MODE, false>;
 }
-static RenderKernel render_kernel(bool moving, int mode)
+static RenderKernel render_kernel(bool moving, int mode, bool resume)
 {
-    if (moving) { if (mode == MODE_BVH_LDS) return render_kernel_for<true, MODE_BVH_LDS>(); if (mode == MODE_BVH) return render_kernel_for<true, MODE_BVH>(); if (mode == MODE_LDS_STRICT) return render_kernel_for<true, MODE_LDS_STRICT>(); return render_kernel_for<true, MODE_LDS_FAST>(); }
-    if (mode == MODE_BVH_LDS) return render_kernel_for<false, MODE_BVH_LDS>(); if (mode == MODE_BVH) return render_kernel_for<false, MODE_BVH>(); if (mode == MODE_LDS_STRICT) return render_kernel_for<false, MODE_LDS_STRICT>(); return render_kernel_for<false, MODE_LDS_FAST>();
+    if (moving) { if (mode == MODE_BVH_LDS) return render_kernel_for<true, MODE_BVH_LDS>(resume); if (mode == MODE_BVH) return render_kernel_for<true, MODE_BVH>(resume); if (mode == MODE_LDS_STRICT) return render_kernel_for<true, MODE_LDS_STRICT>(resume); return render_kernel_for<true, MODE_LDS_FAST>(resume); }
+    if (mode == MODE_BVH_LDS) return render_kernel_for<false, MODE_BVH_LDS>(resume); if (mode == MODE_BVH) return render_kernel_for<false, MODE_BVH>(resume); if (mode == MODE_LDS_STRICT) return render_kernel_for<false, MODE_LDS_STRICT>(resume); return render_kernel_for<false, MODE_LDS_FAST>(resume);
 }
 
 // ================================================================================================ probes
@@ -469,6 +495,9 @@ struct Bind // make the context's device current for the duration of a call
 constexpr size_t kMaxLdsBytes = 128 * 1024; // of the 160 KiB per CU
 constexpr size_t kAccBytesPerWave = 64 * 16;
 constexpr uint32_t kMinResidentWaves = 16; // per CU: below this the LDS-resident tree loses to the tree in HBM
+// BVH traversal: bvh_run's minActive for the tree in LDS and in HBM (book-1 1080p: 105.1 -> 102.2 ms with 8, flat
+// from 6 to 12; 10^6 spheres 4K: 431 -> 594 -> 669 -> 700 Msamples/s with 0, 8, 16, 24); a single-leaf tree (up to 4 spheres) has no stragglers and skips it.
+constexpr uint32_t kExitLanes = 8, kExitLanesHbm = 24, kResumeMinSpheres = 4;
 constexpr uint32_t kLeafBatch = 16; // BVH traversal: lanes gathered at leaves before the leaf code runs (pt_device.h, bvh_closest)
 constexpr size_t kStatWords = 16; // [0..7] counters, [8] unit cursor of the persistent render kernel
 
@@ -536,9 +565,9 @@ constexpr uint32_t kMaxChunks = 4096;  // (the walk in the kernel is linear in t
 constexpr uint64_t kMaxPartialBytes = 4ull << 30; // per-chunk partial images the context may hold
 
 // Workgroups of the render kernel for (moving, mode) one CU holds at this block size and LDS footprint.
-int render_occupancy(pt_ctx* ctx, bool moving, int mode, int block, size_t lds, int* out)
+int render_occupancy(pt_ctx* ctx, bool moving, int mode, bool resume, int block, size_t lds, int* out)
 {
-    const RenderKernel kern = render_kernel(moving, mode);
+    const RenderKernel kern = render_kernel(moving, mode, resume);
     int st = set_lds(ctx, kern, lds);
     if (st != PT_OK) return st;
     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(out, kern, block, lds));
@@ -689,6 +718,10 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         ctx->sc_bvh.bvh = BvhView{ctx->nodes_dev, ctx->sph_dev, ctx->vel_dev, ctx->mat_dev, bv.root_ref, bv.n_spheres};
         ctx->sc_bvh.stack_entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1; // the sentinel + at most one pushed sibling per inner node of a root-to-leaf path (bv.depth of them)
         ctx->sc_bvh.leaf_batch = kLeafBatch;
+        int exitEnv = -1;
+        if (const char* e = getenv("PT_EXIT_LANES")) { int v = atoi(e); if (v >= 0 && v <= 64) exitEnv = v; } // tuning experiments only
+        const bool resumable = bv.n_spheres > kResumeMinSpheres;
+        ctx->sc_bvh.exit_lanes = !resumable ? 0u : exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanesHbm;
         if (const char* e = getenv("PT_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->sc_bvh.leaf_batch = (uint32_t)v; } // tuning experiments only
         ctx->bvh_nodes = bv.n_nodes; ctx->bvh_depth = bv.depth;
         ctx->moving = bv.moving;
@@ -713,6 +746,7 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
             }
             st = upload_f4(ctx, img.data(), img.size() * 4, &ctx->blob_bvh_dev); if (st != PT_OK) return st;
             ctx->sc_bvh_lds = ctx->sc_bvh;
+            ctx->sc_bvh_lds.exit_lanes = !resumable ? 0u : exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanes;
             ctx->sc_bvh_lds.blob = ctx->blob_bvh_dev; ctx->sc_bvh_lds.blob_f4 = (uint32_t)(img.size() / 4);
             for (int k = 0; k < 4; ++k) ctx->sc_bvh_lds.bvh_off[k] = off[k];
             ctx->sc_bvh_lds.bvh = BvhView{nullptr, nullptr, nullptr, matInLds ? nullptr : ctx->mat_dev, bv.root_ref, bv.n_spheres};
@@ -748,7 +782,7 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
         {
             int m2; const SceneArgs* sc2; size_t lds2; int occ = 0;
             if (select_mode(ctx, flags, wv, true, &m2, &sc2, &lds2) != PT_OK) continue;
-            st = render_occupancy(ctx, ctx->moving, m2, (int)(64 * wv), lds2, &occ);
+            st = render_occupancy(ctx, ctx->moving, m2, sc2->exit_lanes != 0, (int)(64 * wv), lds2, &occ);
             if (st != PT_OK) return st;
             if ((uint32_t)occ * wv > (uint32_t)wgPerCu * waves) { waves = wv; wgPerCu = occ; lds = lds2; }
         }
@@ -808,7 +842,7 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     HIPCHK(ctx, hipMemsetAsync(ctx->stats_dev, 0, kStatWords * sizeof(unsigned long long), stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     {
-        const RenderKernel kern = render_kernel(ctx->moving, mode);
+        const RenderKernel kern = render_kernel(ctx->moving, mode, a.sc.exit_lanes != 0);
         st = set_lds(ctx, kern, lds);
         if (st != PT_OK) return st;
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a);

@@ -60,6 +60,12 @@ PT_DEV V3 reflect_direction(V3 dir, V3 n)                                   // g
 // (defined in DESIGN.md "RNG"; pinned by the Random123 known-answer vectors and against the oracle).
 PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* o)
 {
+#ifndef PT_PHILOX_HOIST
+    // The key is wave-uniform (the seed) and so are the ten round keys: left alone, the compiler hoists all twenty out of
+    // the render loop, runs out of scalar registers and parks them in lanes of a vector register (a v_readlane and a
+    // hazard nop per use).  Opaque to the optimiser here, each round key is one scalar add where it is used.
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
 #pragma unroll
     for (int r = 0; r < 10; ++r)
     {

@@ -41,6 +41,7 @@ struct SceneArgs
     uint32_t bvh_off[4]; //   the arrays sit inside the blob at these float4 offsets (nodes, sph, vel, mat)
     uint32_t stack_entries; // per-lane traversal stack capacity carved from LDS (BVH modes)
     uint32_t leaf_batch;    // lanes that must wait at a leaf before the wave runs the leaf code (BVH modes)
+    uint32_t refill_min;
     uint32_t exit_lanes;    // a trip's traversal phase is left once fewer lanes than this still traverse and one is ready to shade
 };
 
@@ -170,7 +171,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
         // ---- refill: every lane without a live path takes the next work item (main.cpp:347-354)
         const bool want = !alive && !retired;
         const unsigned long long need = pt_ballot(want);
-        if (need)
+        if (need && ((uint32_t)__popcll(need) >= a.sc.refill_min || next >= total || pt_ballot(alive) == 0ull))
         {
             if (want)
             {
@@ -498,6 +499,7 @@ constexpr uint32_t kMinResidentWaves = 16; // per CU: below this the LDS-residen
 // BVH traversal: bvh_run's minActive for the tree in LDS and in HBM (book-1 1080p: 105.1 -> 102.2 ms with 8, flat
 // from 6 to 12; 10^6 spheres 4K: 431 -> 594 -> 669 -> 700 Msamples/s with 0, 8, 16, 24); a single-leaf tree (up to 4 spheres) has no stragglers and skips it.
 constexpr uint32_t kExitLanes = 8, kExitLanesHbm = 24, kResumeMinSpheres = 4;
+constexpr uint32_t kRefillMin = 20; // lanes that must be out of work before the wave runs the refill code (render_body)
 constexpr uint32_t kLeafBatch = 16; // BVH traversal: lanes gathered at leaves before the leaf code runs (pt_device.h, bvh_closest)
 constexpr size_t kStatWords = 16; // [0..7] counters, [8] unit cursor of the persistent render kernel
 
@@ -603,6 +605,8 @@ void fill_scene_args(SceneArgs* sc, const pth::Blob& b, const float4* dev, const
     sc->off_velp = b.off_velp; sc->off_groups = b.off_groups; sc->off_smat = b.off_smat; sc->off_planes = b.off_planes; sc->off_pmat = b.off_pmat; sc->off_cam = b.off_cam;
     sc->ns = 2 * b.npairs; sc->npairs = b.npairs; sc->ngroups = b.ngroups; sc->np = np; sc->idx_mask = b.idx_mask;
     sc->t0 = d->t0; sc->t1 = d->t1;
+    sc->refill_min = kRefillMin;
+    if (const char* e = getenv("PT_REFILL_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) sc->refill_min = (uint32_t)v; } // tuning experiments only
 }
 
 } // namespace
@@ -721,6 +725,7 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         int exitEnv = -1;
         if (const char* e = getenv("PT_EXIT_LANES")) { int v = atoi(e); if (v >= 0 && v <= 64) exitEnv = v; } // tuning experiments only
         const bool resumable = bv.n_spheres > kResumeMinSpheres;
+
         ctx->sc_bvh.exit_lanes = !resumable ? 0u : exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanesHbm;
         if (const char* e = getenv("PT_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->sc_bvh.leaf_batch = (uint32_t)v; } // tuning experiments only
         ctx->bvh_nodes = bv.n_nodes; ctx->bvh_depth = bv.depth;

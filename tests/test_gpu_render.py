@@ -77,6 +77,28 @@ def test_render_many_chunks_equals_oracle(renderer, oracle, flags):
         assert bit_equal(img, again)             # units may run on any wave; the frame does not depend on it
 
 
+@pytest.mark.parametrize("exit_lanes,refill_min", [(0, 1), (1, 64), (8, 20), (32, 8), (64, 1), (64, 64)])
+@pytest.mark.parametrize("flags", [0, pt.FLAG_FORCE_BVH])
+def test_scheduling_thresholds_do_not_change_the_samples(renderer, oracle, monkeypatch, exit_lanes, refill_min, flags):
+    """The wave-level scheduling of the BVH kernels -- when a trip leaves its traversal phase with stragglers still under
+    way (queries that span trips), when lanes without work are refilled -- decides WHEN a lane's work is done, never WHAT
+    it is: every setting of the two thresholds (read at upload; 0 = run every query to completion) renders the oracle's
+    sample set, segment for segment."""
+    monkeypatch.setenv("PT_EXIT_LANES", str(exit_lanes))
+    monkeypatch.setenv("PT_REFILL_MIN", str(refill_min))
+    w, h, spp, depth = 52, 36, 10, 50
+    for sid in (1, 3):
+        sa = builtin_scene_arrays(sid, w / h)
+        renderer.upload(to_pt_scene(sa))
+        oh = oracle.scene(sa)
+        img = renderer.render(w, h, 0, spp, depth, seed=21, flags=flags)
+        st = renderer.stats()
+        ref, seg = oracle.render_philox(oh, w, h, 0, spp, depth, seed=21)
+        oracle.scene_free(oh)
+        assert st["samples"] == w * h * spp and st["segments"] == seg, (sid, exit_lanes, refill_min, flags)
+        assert _close_sums(img, ref, spp), (sid, exit_lanes, refill_min, flags)
+
+
 def test_render_brute_force_close_to_oracle(renderer, oracle):
     w, h, spp, depth = 96, 54, 16, 50
     sa = builtin_scene_arrays(1, w / h)

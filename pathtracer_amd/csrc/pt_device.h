@@ -442,6 +442,9 @@ struct QueryCtx // per-lane scratch and counters of the sphere query
 #define PT_QSTAMP(var) do { } while (0)
 #endif
 
+// A wave-uniform value the compiler has lost track of: back into a scalar register.
+PT_DEV uint32_t pt_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 // The traversal of one lane between calls of bvh_run: where it stands (node / leaf reference, or kBvhDone), its stack
 // pointer (the stack itself lives in LDS), the closest hit so far.  A query is trav_begin -> bvh_run (once, or several
 // times when the run is left early) -> the hit record.

@@ -103,6 +103,7 @@ __host__ __device__ inline uint32_t chunk_size(uint32_t remaining, uint32_t rati
     return u;
 }
 
+constexpr uint32_t kStatWords = 16;        // stats buffer: totals [0..7] counters, [8] unit cursor, [9..12] stamps; then one such record per wave
 constexpr uint32_t kWavesPerBlock = 4;     // LDS modes: four waves share one staged copy of the scene
 constexpr uint32_t kWavesPerBlockBvh = 1;  // tree in HBM: nothing to share, one wave per workgroup packs best
 
@@ -132,12 +133,11 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     // sample chunk) pairs -- from one global cursor until it runs dry.  A workgroup's staged copy of the scene then
     // serves many tiles, and no wave's slot idles behind a slower sibling.  Every wave reaches unit >= nunits: the
     // cursor only grows.
-  for (;;)
+    // (A wave's first unit is its own index -- no 7000 atomics on one address at the start of the launch; the cursor
+    // hands out the units behind those.)
+  const uint32_t waveId = pt_uniform(blockIdx.x * nwaves + wave), cursorBase = gridDim.x * nwaves;
+  for (uint32_t unit = waveId; unit < a.nunits;)
   {
-    uint32_t unit = 0;
-    if (lane == 0) unit = atomicAdd(reinterpret_cast<unsigned int*>(a.stats + 8), 1u);
-    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
-    if (unit >= a.nunits) break;
     const uint32_t chunk = unit / a.ntiles, slot = unit - chunk * a.ntiles;
     // Neighbouring tiles cost alike (sky rows are cheap, the sphere field is not): a multiplicative shuffle of the
     // tile order mixes cheap and expensive tiles over the whole launch.
@@ -256,26 +256,40 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
             dst[(size_t)py * a.width + px] = v;
         }
     }
+    if (lane == 0) unit = cursorBase + atomicAdd(reinterpret_cast<unsigned int*>(a.stats + 8), 1u);
+    unit = pt_uniform(unit);
   } // units
-    // ---- statistics: segments of this wave
-    if (MODE == MODE_BVH || MODE == MODE_BVH_LDS)
-    {
-        if (lane == 0) // both tallies are wave-level already
- { atomicAdd(a.stats + 6, (unsigned long long)qc.nodeVisits); atomicAdd(a.stats + 7, (unsigned long long)qc.sphereTests); }
-    }
+    // ---- statistics: every wave leaves its tallies in a slot of its own (plain stores; k_sum_stats adds the slots up).
+    // Atomics on shared counters would be ~36 000 same-address operations in the launch's last microseconds: measured,
+    // they were 0.7 ms -- the whole fixed cost of a small launch.
     for (int o = 32; o > 0; o >>= 1) segs += __shfl_xor(segs, o);
     if (lane == 0)
     {
-        atomicAdd(a.stats, (unsigned long long)segs);
-        atomicAdd(a.stats + 1, (unsigned long long)iters);
-        atomicAdd(a.stats + 5, (unsigned long long)qc.searched);
+        unsigned long long* slot = a.stats + kStatWords * (1u + waveId);
+        slot[0] = segs; slot[1] = iters; slot[5] = qc.searched;
+        slot[6] = (MODE == MODE_BVH || MODE == MODE_BVH_LDS) ? qc.nodeVisits : 0u; // both tallies are wave-level already
+        slot[7] = (MODE == MODE_BVH || MODE == MODE_BVH_LDS) ? qc.sphereTests : 0u;
 #ifdef PT_STAMPS
-        atomicAdd(a.stats + 9, (unsigned long long)qc.innerIters); atomicAdd(a.stats + 10, (unsigned long long)qc.leafIters);
-        atomicAdd(a.stats + 11, qc.cycInner); atomicAdd(a.stats + 12, qc.cycLeaf);
+        slot[2] = cyc_refill; slot[3] = cyc_hit; slot[4] = cyc_shade;
+        slot[9] = qc.innerIters; slot[10] = qc.leafIters; slot[11] = qc.cycInner; slot[12] = qc.cycLeaf;
 #endif
-#ifdef PT_STAMPS
-        atomicAdd(a.stats + 2, cyc_refill); atomicAdd(a.stats + 3, cyc_hit); atomicAdd(a.stats + 4, cyc_shade);
-#endif
+    }
+}
+
+// One workgroup: totals[w] = sum over the wave slots (word 8, the unit cursor, is left alone).
+__global__ void __launch_bounds__(256) k_sum_stats(unsigned long long* stats, uint32_t nslots)
+{
+    __shared__ unsigned long long part[256];
+    const uint32_t w = threadIdx.x & 15u, lane16 = threadIdx.x >> 4; // 16 words x 16 partial sums
+    unsigned long long sum = 0;
+    for (uint32_t i = lane16; i < nslots; i += 16u) sum += stats[kStatWords * (1u + i) + w];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x < 16u && threadIdx.x != 8u)
+    {
+        unsigned long long t = 0;
+        for (uint32_t k = 0; k < 16u; ++k) t += part[k * 16u + threadIdx.x];
+        stats[threadIdx.x] = t;
     }
 }
 
@@ -468,6 +482,7 @@ struct pt_ctx
     float* partial_dev = nullptr; size_t partial_floats = 0; // per-chunk sums of a chunked launch (grown on demand, kept)
     int num_cus = 0;
     unsigned long long* stats_dev = nullptr;
+    uint32_t stat_slots = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int last_mode = MODE_LDS_FAST;
@@ -501,7 +516,6 @@ constexpr uint32_t kMinResidentWaves = 16; // per CU: below this the LDS-residen
 constexpr uint32_t kExitLanes = 8, kExitLanesHbm = 24, kResumeMinSpheres = 4;
 constexpr uint32_t kRefillMin = 20; // lanes that must be out of work before the wave runs the refill code (render_body)
 constexpr uint32_t kLeafBatch = 16; // BVH traversal: lanes gathered at leaves before the leaf code runs (pt_device.h, bvh_closest)
-constexpr size_t kStatWords = 16; // [0..7] counters, [8] unit cursor of the persistent render kernel
 
 uint32_t pick_stride(uint32_t ntiles)
 {
@@ -659,7 +673,8 @@ int pt_hip_create(int device, pt_ctx** out)
     }
     c->lds_limit = kMaxLdsBytes;
     c->num_cus = prop.multiProcessorCount;
-    if (hipMalloc((void**)&c->stats_dev, kStatWords * sizeof(unsigned long long)) != hipSuccess ||
+    c->stat_slots = (uint32_t)c->num_cus * 32u; // no launch holds more waves than the chip's 32 per CU
+    if (hipMalloc((void**)&c->stats_dev, (size_t)kStatWords * (1u + c->stat_slots) * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
     {
         pt_hip_destroy(c);
@@ -844,7 +859,9 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     const dim3 grid((uint32_t)wgs);
     if (getenv("PT_VERBOSE"))
         fprintf(stderr, "pt_hip: render mode %d, %u waves/WG, LDS %zu B/WG, %d WG/CU, grid %u, %u tiles x %u chunks\n", mode, waves, lds, wgPerCu, grid.x, a.ntiles, nchunks);
-    HIPCHK(ctx, hipMemsetAsync(ctx->stats_dev, 0, kStatWords * sizeof(unsigned long long), stream));
+    const uint32_t nslots = grid.x * waves;
+    if (nslots > ctx->stat_slots) { ctx->err = "launch larger than the statistics buffer"; return PT_ERR_UNSUPPORTED; }
+    HIPCHK(ctx, hipMemsetAsync(ctx->stats_dev, 0, (size_t)kStatWords * (1u + nslots) * sizeof(unsigned long long), stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     {
         const RenderKernel kern = render_kernel(ctx->moving, mode, a.sc.exit_lanes != 0);
@@ -860,6 +877,8 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(k_fold_chunks, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(ctx->partial_dev), nchunks, n, reinterpret_cast<float4*>(accum_dev));
     }
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, stream, ctx->stats_dev, nslots);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;

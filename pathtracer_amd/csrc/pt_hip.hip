@@ -136,34 +136,43 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     // (A wave's first unit is its own index -- no 7000 atomics on one address at the start of the launch; the cursor
     // hands out the units behind those.)
   const uint32_t waveId = pt_uniform(blockIdx.x * nwaves + wave), cursorBase = gridDim.x * nwaves;
-  for (uint32_t unit = waveId; unit < a.nunits;)
-  {
-    const uint32_t chunk = unit / a.ntiles, slot = unit - chunk * a.ntiles;
-    // Neighbouring tiles cost alike (sky rows are cheap, the sphere field is not): a multiplicative shuffle of the
-    // tile order mixes cheap and expensive tiles over the whole launch.
-    const uint32_t tile = (uint32_t)(((unsigned long long)slot * a.tile_stride) % a.ntiles);
-    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    uint32_t s0 = 0, s1 = 0; // samples [s0, s1) of the call: walk the schedule up to this chunk (scalar work, once per unit)
-    for (uint32_t c = 0;; ++c)
-    {
-        s1 = s0 + chunk_size(a.nspp - s0, a.chunk_ratio_q16, a.chunk_min);
-        if (c == chunk) break;
-        s0 = s1;
-    }
-    acc[lane] = 0.0f; acc[lane + 64] = 0.0f; acc[lane + 128] = 0.0f; acc[lane + 192] = 0.0f;
-
-    const uint32_t total = 64u * (s1 - s0); // work items of this unit: item i = (pixel i&63 of the tile, sample s0 + (i>>6))
-    uint32_t next = 0;                      // wave-uniform cursor into the pool
-    bool alive = false, retired = false;
+    // Per-lane path state.  It outlives the unit: when a unit's pool runs dry the paths still under way are CARRIED into
+    // the next unit's trips (no drain with a handful of lanes); such a path adds its result straight to its own unit's
+    // pixel in HBM (kCarried | pixel index in p) instead of the tile accumulator, which by then belongs to the next unit.
+    bool alive = false;
     // The live ray is kept as six scalars: as a struct it stays an un-promoted alloca (scratch traffic in the loop).
     float rox = 0, roy = 0, roz = 0, rdx = 0, rdy = 0, rdz = 1;
     V4 T = v4(1, 1, 1, 1);
     float time = 0.0f;
     uint32_t depth = 0, p = 0;
+    constexpr uint32_t kCarried = 0x80000000u;
+    float* const image = a.nchunks > 1u ? a.partial : a.out_sum;
     // BVH kernels: a lane's sphere query may span several trips (bvh_run's early exit); ts.cur != kBvhDone marks a
     // lane whose query is under way.
     constexpr bool kBvh = RESUME && (MODE == MODE_BVH || MODE == MODE_BVH_LDS);
     TravState ts; ts.cur = kBvhDone; ts.best = 0.0f; ts.bestSlot = -1; ts.pk = 0;
+  for (uint32_t unit = waveId;;)
+  {
+    const bool haveUnit = unit < a.nunits;     // false: the launch's last trips, carried paths only
+    if (!haveUnit && pt_ballot(alive) == 0ull) break;
+    const uint32_t chunk = haveUnit ? unit / a.ntiles : 0u, slot = unit - chunk * a.ntiles;
+    // Neighbouring tiles cost alike (sky rows are cheap, the sphere field is not): a multiplicative shuffle of the
+    // tile order mixes cheap and expensive tiles over the whole launch.
+    const uint32_t tile = haveUnit ? (uint32_t)(((unsigned long long)slot * a.tile_stride) % a.ntiles) : 0u;
+    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    uint32_t s0 = 0, s1 = 0; // samples [s0, s1) of the call: walk the schedule up to this chunk (scalar work, once per unit)
+    if (haveUnit)
+        for (uint32_t c = 0;; ++c)
+        {
+            s1 = s0 + chunk_size(a.nspp - s0, a.chunk_ratio_q16, a.chunk_min);
+            if (c == chunk) break;
+            s0 = s1;
+        }
+    acc[lane] = 0.0f; acc[lane + 64] = 0.0f; acc[lane + 128] = 0.0f; acc[lane + 192] = 0.0f;
+
+    const uint32_t total = 64u * (s1 - s0); // work items of this unit: item i = (pixel i&63 of the tile, sample s0 + (i>>6))
+    uint32_t next = 0;                      // wave-uniform cursor into the pool
+    bool retired = false;
 
     for (;;)
     {
@@ -197,9 +206,16 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
             }
             next += (uint32_t)__popcll(need);
         }
+        if (haveUnit && next >= total)
+        {
+            // The pool is empty: whoever is still under way is carried (its tile pixel becomes an index into the image).
+            if (alive && !(p & kCarried))
+                p = kCarried | (chunk * (a.width * a.height) + (ty * 8u + (p >> 3)) * a.width + tx * 8u + (p & 7u));
+            break;
+        }
         if (pt_ballot(alive) == 0ull)
         {
-            if (next >= total) break;
+            if (!haveUnit) break;
             continue;
         }
         // ---- one segment for every lane (lanes without a live path ride along on stale data)
@@ -235,8 +251,16 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
             if (ended)
             {
                 const V4 c = hadamard(T, terminal);
-                atomicAdd(&acc[p * 4u + 0u], c.x); atomicAdd(&acc[p * 4u + 1u], c.y);
-                atomicAdd(&acc[p * 4u + 2u], c.z); atomicAdd(&acc[p * 4u + 3u], c.w);
+                if (p & kCarried)
+                {
+                    float* dst = image + 4u * (size_t)(p & ~kCarried);
+                    unsafeAtomicAdd(dst, c.x); unsafeAtomicAdd(dst + 1, c.y); unsafeAtomicAdd(dst + 2, c.z); unsafeAtomicAdd(dst + 3, c.w);
+                }
+                else
+                {
+                    atomicAdd(&acc[p * 4u + 0u], c.x); atomicAdd(&acc[p * 4u + 1u], c.y);
+                    atomicAdd(&acc[p * 4u + 2u], c.z); atomicAdd(&acc[p * 4u + 3u], c.w);
+                }
                 alive = false;
             }
         }
@@ -246,18 +270,20 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
 #endif
     }
 
-    // ---- one 16-byte store per pixel and unit: the only HBM traffic of the render besides staging the scene
+    // ---- one 16-byte store per pixel and unit (plus the carried paths' atomics: the only HBM traffic of the render
+    // besides staging the scene).  The store must have landed before a carried path of this unit adds to it.
+    if (haveUnit)
     {
         const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
         if (px < a.width && py < a.height)
         {
             float4 v = make_float4(acc[lane * 4u], acc[lane * 4u + 1u], acc[lane * 4u + 2u], acc[lane * 4u + 3u]);
-            float4* dst = a.nchunks > 1u ? reinterpret_cast<float4*>(a.partial) + (size_t)chunk * a.width * a.height : reinterpret_cast<float4*>(a.out_sum);
-            dst[(size_t)py * a.width + px] = v;
+            reinterpret_cast<float4*>(image)[(size_t)chunk * a.width * a.height + (size_t)py * a.width + px] = v;
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+        if (lane == 0) unit = cursorBase + atomicAdd(reinterpret_cast<unsigned int*>(a.stats + 8), 1u);
+        unit = pt_uniform(unit);
     }
-    if (lane == 0) unit = cursorBase + atomicAdd(reinterpret_cast<unsigned int*>(a.stats + 8), 1u);
-    unit = pt_uniform(unit);
   } // units
     // ---- statistics: every wave leaves its tallies in a slot of its own (plain stores; k_sum_stats adds the slots up).
     // Atomics on shared counters would be ~36 000 same-address operations in the launch's last microseconds: measured,

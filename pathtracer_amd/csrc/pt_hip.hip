@@ -90,9 +90,9 @@ struct RenderArgs
     unsigned long long* stats;      // [0] segments ... [8] low word: the unit cursor the waves pull from
 };
 
-// Guided schedule of the sample chunks: big chunks first, small ones last.  Every unit ends with a drain (lanes idle
-// while the unit's last paths finish), so few units are wanted; the launch's tail is as long as its last units, so
-// small ones are wanted at the end.  A chunk takes the share `ratio` of the samples still to do (at most half, at least
+// Guided schedule of the sample chunks: big chunks first, small ones last.  Every unit has fixed costs (this walk, the
+// tile flush, a partial image to fold, the cursor's round trip), so few units are wanted; the launch's tail is as long
+// as its last units, so small ones are wanted at the end.  A chunk takes the share `ratio` of the samples still to do (at most half, at least
 // `minSpp`; a remainder below 2 x minSpp goes in one piece).  Host and device run the same recurrence.
 __host__ __device__ inline uint32_t chunk_size(uint32_t remaining, uint32_t ratio_q16, uint32_t minSpp)
 {

@@ -75,11 +75,18 @@ typedef struct pt_params {
  *                        formulation of BASELINE.json's north star; approximate search + exact re-evaluation)
  *   PT_FLAG_STRICT_SEARCH: brute force in reference arithmetic for every sphere (slow; parity tests)
  *   PT_FLAG_FORCE_BVH  : BVH traversal from HBM even if the scene fits in LDS
- *   PT_FLAG_FORCE_LDS  : fail with PT_ERR_UNSUPPORTED rather than read the scene from HBM */
+ *   PT_FLAG_FORCE_LDS  : fail with PT_ERR_UNSUPPORTED rather than read the scene from HBM
+ * How the per-pixel sums are formed (the samples are the same either way, each exactly once):
+ *   default            : a wave starts its next (tile, sample-chunk) unit while the last paths of the previous one are
+ *                        still under way; the order of the float additions into a pixel then depends on the run, and
+ *                        two renders of one frame can differ in the last bits of a sum (a few ulp)
+ *   PT_FLAG_REPRODUCIBLE: every unit is finished before the next one starts: the same launch gives the same bits,
+ *                        run to run (~6 % slower on the bench workload) */
 #define PT_FLAG_STRICT_SEARCH 1u
 #define PT_FLAG_FORCE_BVH 2u
 #define PT_FLAG_FORCE_LDS 4u
 #define PT_FLAG_BRUTE_FORCE 8u
+#define PT_FLAG_REPRODUCIBLE 16u
 
 typedef struct pt_stats {
     uint64_t samples;       /* width*height*(spp_end-spp_begin) */

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
 PT_OK = 0
 PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_UNSUPPORTED, PT_ERR_IO = -1, -2, -3, -4, -5, -6
 MAT_NONE, MAT_DIFFUSE, MAT_METAL, MAT_DIALECTRIC = 0, 1, 2, 3
-FLAG_STRICT_SEARCH, FLAG_FORCE_BVH, FLAG_FORCE_LDS, FLAG_BRUTE_FORCE = 1, 2, 4, 8
+FLAG_STRICT_SEARCH, FLAG_FORCE_BVH, FLAG_FORCE_LDS, FLAG_BRUTE_FORCE, FLAG_REPRODUCIBLE = 1, 2, 4, 8, 16
 PRIM_MISS = -(2 ** 31)
 
 # Every symbol include/pt_hip.h declares (tests/test_abi.py checks the library exports exactly these).

@@ -108,7 +108,7 @@ constexpr uint32_t kWavesPerBlock = 4;     // LDS modes: four waves share one st
 constexpr uint32_t kWavesPerBlockBvh = 1;  // tree in HBM: nothing to share, one wave per workgroup packs best
 
 // ================================================================================================ the hot kernel
-template <bool MOVING, int MODE, bool RESUME>
+template <bool MOVING, int MODE, bool RESUME, bool CARRY>
 __device__ __forceinline__ void render_body(const RenderArgs& a)
 {
     extern __shared__ float4 smem[];
@@ -206,7 +206,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
             }
             next += (uint32_t)__popcll(need);
         }
-        if (haveUnit && next >= total)
+        if (CARRY && haveUnit && next >= total)
         {
             // The pool is empty: whoever is still under way is carried (its tile pixel becomes an index into the image).
             if (alive && !(p & kCarried))
@@ -215,7 +215,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
         }
         if (pt_ballot(alive) == 0ull)
         {
-            if (!haveUnit) break;
+            if (CARRY ? !haveUnit : next >= total) break;
             continue;
         }
         // ---- one segment for every lane (lanes without a live path ride along on stale data)
@@ -325,29 +325,37 @@ __global__ void __launch_bounds__(256) k_sum_stats(unsigned long long* stats, ui
 // to the compiler.
 // RESUME: sphere queries that may span trips (bvh_run); scenes with a handful of spheres do without (the carried state
 // costs them 3 %).
-template <bool MOVING, int MODE> __global__ void __launch_bounds__(512) k_render(RenderArgs a) { render_body<MOVING, MODE, false>(a); }
+// CARRY: paths still under way when a unit's pool runs dry ride along in the next unit (false: PT_FLAG_REPRODUCIBLE).
+template <bool MOVING, int MODE, bool CARRY> __global__ void __launch_bounds__(512) k_render(RenderArgs a) { render_body<MOVING, MODE, false, CARRY>(a); }
 #ifdef PT_NO_EU
 #define PT_EU(n)
 #else
 #define PT_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
-template <bool MOVING, int MODE, bool RESUME> __global__ void __launch_bounds__(512) PT_EU(6) k_render_w6(RenderArgs a) { render_body<MOVING, MODE, RESUME>(a); }
+template <bool MOVING, int MODE, bool RESUME, bool CARRY> __global__ void __launch_bounds__(512) PT_EU(6) k_render_w6(RenderArgs a) { render_body<MOVING, MODE, RESUME, CARRY>(a); }
 #ifndef PT_LDS_WAVES
 #define PT_LDS_WAVES 7 // experiments: make variant DEFS=-DPT_LDS_WAVES=6
 #endif
-template <bool MOVING, int MODE, bool RESUME> __global__ void __launch_bounds__(512) PT_EU(PT_LDS_WAVES) k_render_w7(RenderArgs a) { render_body<MOVING, MODE, RESUME>(a); }
+template <bool MOVING, int MODE, bool RESUME, bool CARRY> __global__ void __launch_bounds__(512) PT_EU(PT_LDS_WAVES) k_render_w7(RenderArgs a) { render_body<MOVING, MODE, RESUME, CARRY>(a); }
 using RenderKernel = void (*)(RenderArgs);
-template <bool MOVING, int MODE> RenderKernel render_kernel_for(bool resume)
+template <bool MOVING, int MODE, bool CARRY> RenderKernel render_kernel_for(bool resume)
 {
-    if constexpr (MODE == MODE_BVH_LDS) return resume ? &k_render_w7<MOVING, MODE, true> : &k_render_w7<MOVING, MODE, false>;
-    else if constexpr (MODE == MODE_BVH) return resume ? &k_render_w6<MOVING, MODE, true> : &k_render_w6<MOVING, MODE, false>;
-    else if constexpr (MODE == MODE_LDS_STRICT) return &k_render<MOVING, MODE>;
-    else return &k_render_w6<MOVING, MODE, false>;
+    if constexpr (MODE == MODE_BVH_LDS) return resume ? &k_render_w7<MOVING, MODE, true, CARRY> : &k_render_w7<MOVING, MODE, false, CARRY>;
+    else if constexpr (MODE == MODE_BVH) return resume ? &k_render_w6<MOVING, MODE, true, CARRY> : &k_render_w6<MOVING, MODE, false, CARRY>;
+    else if constexpr (MODE == MODE_LDS_STRICT) return &k_render<MOVING, MODE, CARRY>;
+    else return &k_render_w6<MOVING, MODE, false, CARRY>;
 }
-static RenderKernel render_kernel(bool moving, int mode, bool resume)
+template <bool MOVING, bool CARRY> RenderKernel render_kernel_mc(int mode, bool resume)
 {
-    if (moving) { if (mode == MODE_BVH_LDS) return render_kernel_for<true, MODE_BVH_LDS>(resume); if (mode == MODE_BVH) return render_kernel_for<true, MODE_BVH>(resume); if (mode == MODE_LDS_STRICT) return render_kernel_for<true, MODE_LDS_STRICT>(resume); return render_kernel_for<true, MODE_LDS_FAST>(resume); }
-    if (mode == MODE_BVH_LDS) return render_kernel_for<false, MODE_BVH_LDS>(resume); if (mode == MODE_BVH) return render_kernel_for<false, MODE_BVH>(resume); if (mode == MODE_LDS_STRICT) return render_kernel_for<false, MODE_LDS_STRICT>(resume); return render_kernel_for<false, MODE_LDS_FAST>(resume);
+    if (mode == MODE_BVH_LDS) return render_kernel_for<MOVING, MODE_BVH_LDS, CARRY>(resume);
+    if (mode == MODE_BVH) return render_kernel_for<MOVING, MODE_BVH, CARRY>(resume);
+    if (mode == MODE_LDS_STRICT) return render_kernel_for<MOVING, MODE_LDS_STRICT, CARRY>(resume);
+    return render_kernel_for<MOVING, MODE_LDS_FAST, CARRY>(resume);
+}
+static RenderKernel render_kernel(bool moving, int mode, bool resume, bool carry)
+{
+    if (moving) return carry ? render_kernel_mc<true, true>(mode, resume) : render_kernel_mc<true, false>(mode, resume);
+    return carry ? render_kernel_mc<false, true>(mode, resume) : render_kernel_mc<false, false>(mode, resume);
 }
 
 // ================================================================================================ probes
@@ -607,9 +615,9 @@ constexpr uint32_t kMaxChunks = 4096;  // (the walk in the kernel is linear in t
 constexpr uint64_t kMaxPartialBytes = 4ull << 30; // per-chunk partial images the context may hold
 
 // Workgroups of the render kernel for (moving, mode) one CU holds at this block size and LDS footprint.
-int render_occupancy(pt_ctx* ctx, bool moving, int mode, bool resume, int block, size_t lds, int* out)
+int render_occupancy(pt_ctx* ctx, bool moving, int mode, bool resume, bool carry, int block, size_t lds, int* out)
 {
-    const RenderKernel kern = render_kernel(moving, mode, resume);
+    const RenderKernel kern = render_kernel(moving, mode, resume, carry);
     int st = set_lds(ctx, kern, lds);
     if (st != PT_OK) return st;
     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(out, kern, block, lds));
@@ -828,7 +836,7 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
         {
             int m2; const SceneArgs* sc2; size_t lds2; int occ = 0;
             if (select_mode(ctx, flags, wv, true, &m2, &sc2, &lds2) != PT_OK) continue;
-            st = render_occupancy(ctx, ctx->moving, m2, sc2->exit_lanes != 0, (int)(64 * wv), lds2, &occ);
+            st = render_occupancy(ctx, ctx->moving, m2, sc2->exit_lanes != 0, !(p->flags & PT_FLAG_REPRODUCIBLE), (int)(64 * wv), lds2, &occ);
             if (st != PT_OK) return st;
             if ((uint32_t)occ * wv > (uint32_t)wgPerCu * waves) { waves = wv; wgPerCu = occ; lds = lds2; }
         }
@@ -890,7 +898,7 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     HIPCHK(ctx, hipMemsetAsync(ctx->stats_dev, 0, (size_t)kStatWords * (1u + nslots) * sizeof(unsigned long long), stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     {
-        const RenderKernel kern = render_kernel(ctx->moving, mode, a.sc.exit_lanes != 0);
+        const RenderKernel kern = render_kernel(ctx->moving, mode, a.sc.exit_lanes != 0, !(p->flags & PT_FLAG_REPRODUCIBLE));
         st = set_lds(ctx, kern, lds);
         if (st != PT_OK) return st;
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a);

@@ -73,8 +73,10 @@ def test_render_many_chunks_equals_oracle(renderer, oracle, flags):
         assert st["samples"] == w * h * spp and st["segments"] == seg, (sid, flags)
         assert _close_sums(img, ref, spp), (sid, flags)
         assert np.allclose(img[..., 3], spp, rtol=1e-6)
-        again = renderer.render(w, h, 3, 3 + spp, depth, seed=11, flags=flags)
-        assert bit_equal(img, again)             # units may run on any wave; the frame does not depend on it
+        again = renderer.render(w, h, 3, 3 + spp, depth, seed=11, flags=flags | pt.FLAG_REPRODUCIBLE)
+        twice = renderer.render(w, h, 3, 3 + spp, depth, seed=11, flags=flags | pt.FLAG_REPRODUCIBLE)
+        assert bit_equal(again, twice)           # units may run on any wave; with this flag the frame does not depend on it
+        assert _close_sums(again, ref, spp)
 
 
 @pytest.mark.parametrize("exit_lanes,refill_min", [(0, 1), (1, 64), (8, 20), (32, 8), (64, 1), (64, 64)])
@@ -97,6 +99,23 @@ def test_scheduling_thresholds_do_not_change_the_samples(renderer, oracle, monke
         oracle.scene_free(oh)
         assert st["samples"] == w * h * spp and st["segments"] == seg, (sid, exit_lanes, refill_min, flags)
         assert _close_sums(img, ref, spp), (sid, exit_lanes, refill_min, flags)
+
+
+def test_reproducible_flag_gives_the_same_bits_run_to_run(renderer):
+    """A launch big enough that every wave works through several units.  By default a wave starts its next unit while
+    paths of the previous one are still under way, so the order of the additions into a pixel depends on the run: same
+    samples, sums equal to a few ulp.  PT_FLAG_REPRODUCIBLE finishes every unit first: identical bits."""
+    w, h, spp, depth = 960, 540, 48, 50
+    renderer.upload(pt.Scene.builtin(1, w / h))
+    for flags in (pt.FLAG_REPRODUCIBLE, pt.FLAG_REPRODUCIBLE | pt.FLAG_FORCE_BVH):
+        a = renderer.render(w, h, 0, spp, depth, seed=9, flags=flags)
+        sa = renderer.stats()
+        b = renderer.render(w, h, 0, spp, depth, seed=9, flags=flags)
+        assert bit_equal(a, b), flags
+        c = renderer.render(w, h, 0, spp, depth, seed=9, flags=flags & ~pt.FLAG_REPRODUCIBLE)
+        sc = renderer.stats()
+        assert sa["segments"] == sc["segments"] and sa["samples"] == sc["samples"] == w * h * spp
+        assert _close_sums(c, a, spp), flags
 
 
 def test_render_brute_force_close_to_oracle(renderer, oracle):

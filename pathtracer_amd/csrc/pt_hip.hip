@@ -302,20 +302,27 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     }
 }
 
-// One workgroup: totals[w] = sum over the wave slots (word 8, the unit cursor, is left alone).
+// totals[w] += sum over the wave slots (word 8, the unit cursor, is left alone; the totals were zeroed before the
+// render).  A workgroup takes 256 slots: thread (g, w) adds word w of 16 of them (independent loads), LDS folds the 16
+// groups, 15 atomics per workgroup -- a few hundred in all.
 __global__ void __launch_bounds__(256) k_sum_stats(unsigned long long* stats, uint32_t nslots)
 {
     __shared__ unsigned long long part[256];
-    const uint32_t w = threadIdx.x & 15u, lane16 = threadIdx.x >> 4; // 16 words x 16 partial sums
+    const uint32_t w = threadIdx.x & 15u, g = threadIdx.x >> 4;
     unsigned long long sum = 0;
-    for (uint32_t i = lane16; i < nslots; i += 16u) sum += stats[kStatWords * (1u + i) + w];
+#pragma unroll
+    for (uint32_t j = 0; j < 16u; ++j)
+    {
+        const uint32_t slot = blockIdx.x * 256u + g + 16u * j;
+        if (slot < nslots) sum += stats[kStatWords * (1u + slot) + w];
+    }
     part[threadIdx.x] = sum;
     __syncthreads();
     if (threadIdx.x < 16u && threadIdx.x != 8u)
     {
         unsigned long long t = 0;
         for (uint32_t k = 0; k < 16u; ++k) t += part[k * 16u + threadIdx.x];
-        stats[threadIdx.x] = t;
+        if (t) atomicAdd(stats + threadIdx.x, t);
     }
 }
 
@@ -912,7 +919,7 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
         hipLaunchKernelGGL(k_fold_chunks, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(ctx->partial_dev), nchunks, n, reinterpret_cast<float4*>(accum_dev));
     }
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, stream, ctx->stats_dev, nslots);
+    hipLaunchKernelGGL(k_sum_stats, dim3((nslots + 255u) / 256u), dim3(256), 0, stream, ctx->stats_dev, nslots);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;

@@ -118,7 +118,10 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* scene);
 int pt_hip_render(pt_ctx* ctx, const pt_params* params, float* accum_rgba_host);
 
 /* Same, into caller-owned DEVICE memory on a caller-owned stream (hipStream_t as void*; NULL = default stream).
- * Asynchronous: returns after enqueueing.  This is what a multi-GPU driver all-reduces (RCCL) before resolving. */
+ * Asynchronous: returns after enqueueing.  This is what a multi-GPU driver all-reduces (RCCL) before resolving.
+ * accum_rgba_dev: 16-byte aligned, ordinary device memory of this GPU (hipMalloc / a torch CUDA tensor): without
+ * PT_FLAG_REPRODUCIBLE the kernel may add to it with hardware FP32 atomics, which fine-grained or host-mapped
+ * allocations do not guarantee. */
 int pt_hip_render_device(pt_ctx* ctx, const pt_params* params, float* accum_rgba_dev, void* stream);
 
 /* Statistics of the last render on this context (synchronises with it). */

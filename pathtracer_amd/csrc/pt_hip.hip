@@ -339,7 +339,10 @@ template <bool MOVING, int MODE, bool CARRY> __global__ void __launch_bounds__(5
 #else
 #define PT_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
-template <bool MOVING, int MODE, bool RESUME, bool CARRY> __global__ void __launch_bounds__(512) PT_EU(6) k_render_w6(RenderArgs a) { render_body<MOVING, MODE, RESUME, CARRY>(a); }
+#ifndef PT_HBM_WAVES
+#define PT_HBM_WAVES 6 // experiments: make variant DEFS=-DPT_HBM_WAVES=7
+#endif
+template <bool MOVING, int MODE, bool RESUME, bool CARRY> __global__ void __launch_bounds__(512) PT_EU(PT_HBM_WAVES) k_render_w6(RenderArgs a) { render_body<MOVING, MODE, RESUME, CARRY>(a); }
 #ifndef PT_LDS_WAVES
 #define PT_LDS_WAVES 7 // experiments: make variant DEFS=-DPT_LDS_WAVES=6
 #endif

@@ -101,6 +101,25 @@ def test_scheduling_thresholds_do_not_change_the_samples(renderer, oracle, monke
         assert _close_sums(img, ref, spp), (sid, exit_lanes, refill_min, flags)
 
 
+@pytest.mark.parametrize("sid,w,h,spp", [(1, 640, 360, 64), (3, 512, 288, 40)])
+def test_render_many_units_per_wave_equals_oracle(renderer, oracle, sid, w, h, spp):
+    """A launch with several times more (tile, chunk) units than resident waves (28 800 vs 7 168): paths are carried from
+    unit to unit, queries span trips, the launch ends on carried paths -- and it is still the oracle's sample set,
+    segment for segment, through every kernel family."""
+    depth = 50
+    sa = builtin_scene_arrays(sid, w / h)
+    renderer.upload(to_pt_scene(sa))
+    oh = oracle.scene(sa)
+    ref, seg = oracle.render_philox(oh, w, h, 0, spp, depth, seed=77)
+    oracle.scene_free(oh)
+    for flags in (0, pt.FLAG_REPRODUCIBLE, pt.FLAG_FORCE_BVH, pt.FLAG_FORCE_BVH | pt.FLAG_REPRODUCIBLE):
+        img = renderer.render(w, h, 0, spp, depth, seed=77, flags=flags)
+        st = renderer.stats()
+        assert st["samples"] == w * h * spp and st["segments"] == seg, (sid, flags)
+        assert _close_sums(img, ref, spp), (sid, flags)
+        assert np.allclose(img[..., 3], spp, rtol=1e-6)
+
+
 def test_reproducible_flag_gives_the_same_bits_run_to_run(renderer):
     """A launch big enough that every wave works through several units.  By default a wave starts its next unit while
     paths of the previous one are still under way, so the order of the additions into a pixel depends on the run: same

@@ -7,7 +7,8 @@ CSRC     := pathtracer_amd/csrc
 HOST     := pathtracer_amd/host
 # -ffp-contract=off: value-carrying arithmetic keeps the reference's rounding; the sphere search re-enables
 # contraction locally with `#pragma clang fp contract(fast)` (pt_device.h).
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
+# -amdgpu-sched-strategy=max-ilp: +1 % on the bench kernel against the default strategy (tools/ab.py), none of the others measured better
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-sched-strategy=max-ilp -Wall -Wno-unused-function
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Wall
 
 BINDIR   := pathtracer_amd/bin

@@ -533,7 +533,10 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
             q.nodeVisits += nInner;                                      // wave-level tally
             if (atInner)
             {
-                const float4 n0 = b.nodes[4 * cur], n1 = b.nodes[4 * cur + 1], n2 = b.nodes[4 * cur + 2], n3 = b.nodes[4 * cur + 3];
+                const float4 n0 = b.nodes[4 * cur], n1 = b.nodes[4 * cur + 1], n2 = b.nodes[4 * cur + 2];
+                // the two references are half of the node's last 16 bytes: an 8-byte load (from HBM the compiler would
+                // fetch all 16, and the tree-in-HBM kernel is bound by the bytes the L1 hands back per lane)
+                const float2 n3 = *reinterpret_cast<const float2*>(b.nodes + 4 * cur + 3);
                 // left box {n0.xyz .. n0.w, n1.x, n1.y}, right box {n1.z, n1.w, n2.x .. n2.yzw}
                 float nearL, nearR;
                 const bool hitL = CONE ? box_hit_cone(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearL)

@@ -261,4 +261,61 @@ inline void build_bvh(const pt_scene_desc* d, BvhData* out)
     }
 }
 
+// ---- 32-byte nodes for big trees in HBM -------------------------------------------------------------------------------
+// Every child-box coordinate on a 16-bit grid over the scene's box (lo rounded down, hi rounded up: the decoded box
+// encloses the padded float box), two boxes + two references = 32 bytes, same node order and references as the float
+// nodes:   q0 = {L.x, L.y, L.z, R.x}  q1 = {R.y, R.z, refL, refR}   with  .x = lo.x | hi.x << 16  etc.
+// The device never decodes a plane: with  plane = org + g * step  the slab value is
+//     (plane - o) * r  =  g * (step * r) + (org * r - o * r),
+// two per-ray constants per plane set up once per query, then one conversion and one FMA per plane (pt_device.h).
+// Half the bytes per node halves the vector loads and the lines a wave step pulls through the L1.
+struct NodeGrid { float org[3], step[3]; };
+inline void quantise_nodes(const BvhData& in, NodeGrid* grid, std::vector<uint32_t>* out)
+{
+    out->clear();
+    for (int k = 0; k < 3; ++k) { grid->org[k] = 0.0f; grid->step[k] = 1.0f; }
+    if (in.n_nodes == 0) return;
+    double lo[3] = {3e38, 3e38, 3e38}, hi[3] = {-3e38, -3e38, -3e38};
+    for (uint32_t i = 0; i < in.n_nodes; ++i)
+    {
+        const float* nd = in.nodes.data() + 16 * (size_t)i;
+        for (int k = 0; k < 3; ++k)
+        {
+            lo[k] = std::min(lo[k], (double)std::min(nd[k], nd[6 + k]));
+            hi[k] = std::max(hi[k], (double)std::max(nd[3 + k], nd[9 + k]));
+        }
+    }
+    for (int k = 0; k < 3; ++k)
+    {
+        grid->org[k] = (float)lo[k];
+        if ((double)grid->org[k] > lo[k]) grid->org[k] = nextafterf(grid->org[k], -INFINITY);
+        double st = (hi[k] - (double)grid->org[k]) / 65535.0 * (1.0 + 1e-6);
+        if (!(st > 1e-30)) st = 1e-30;
+        grid->step[k] = (float)st;
+        if ((double)grid->step[k] < st) grid->step[k] = nextafterf(grid->step[k], INFINITY);
+    }
+    out->resize(8 * (size_t)in.n_nodes);
+    auto cell = [&](float v, int k, bool up) -> uint32_t {
+        const double org = grid->org[k], st = grid->step[k];
+        double g = up ? ceil(((double)v - org) / st) : floor(((double)v - org) / st);
+        if (g < 0) g = 0;
+        if (g > 65535) g = 65535;
+        // the division rounds: make sure of the side
+        if (up) { while (g < 65535 && org + g * st < (double)v) g += 1; }
+        else { while (g > 0 && org + g * st > (double)v) g -= 1; }
+        return (uint32_t)g;
+    };
+    for (uint32_t i = 0; i < in.n_nodes; ++i)
+    {
+        const float* nd = in.nodes.data() + 16 * (size_t)i;
+        uint32_t* q = out->data() + 8 * (size_t)i;
+        for (int k = 0; k < 3; ++k)
+        {
+            q[k] = cell(nd[k], k, false) | cell(nd[3 + k], k, true) << 16;          // left child
+            q[3 + k] = cell(nd[6 + k], k, false) | cell(nd[9 + k], k, true) << 16;  // right child
+        }
+        q[6] = f2u(nd[12]); q[7] = f2u(nd[13]);
+    }
+}
+
 } // namespace pth

@@ -371,6 +371,7 @@ struct BvhView
 {
     const float4* nodes; const float4* sph; const float4* vel; const float4* mat;
     uint32_t root_ref, n_spheres;
+    float gorg[3], gstep[3]; // MODE_BVH_Q: the grid of the 32-byte nodes (pt_bvh.h, quantise_nodes)
 };
 
 PT_DEV bool sphere_clearly_missed(const Ray& ray, V3 c, float r2)
@@ -407,8 +408,10 @@ PT_DEV bool box_hit(float lox, float loy, float loz, float hix, float hiy, float
 // brute-force search in that arithmetic -- the definition of the query -- finds them; the cone makes the tree visit them.
 constexpr float kConeEps = 1.0e-3f;
 PT_DEV bool cone_flat(float d) { return !(fabsf(d) > kConeEps * 1.001f); } // the cone outgrows this axis
-PT_DEV bool box_hit_cone(float lox, float loy, float loz, float hix, float hiy, float hiz, float r1x, float r1y, float r1z, float n1x, float n1y, float n1z,
-                         float r2x, float r2y, float r2z, float n2x, float n2y, float n2z, bool anyFlat, V3 d, float best, float* tnear)
+// lo planes go with (r2, n2), hi planes with (r1, n1); the coordinates are floats (64-byte nodes) or grid cells (32-byte
+// nodes, whose grid is folded into the pairs)
+PT_DEV bool cone_planes(float lox, float hix, float loy, float hiy, float loz, float hiz, float r1x, float r1y, float r1z, float n1x, float n1y, float n1z,
+                        float r2x, float r2y, float r2z, float n2x, float n2y, float n2z, bool anyFlat, V3 d, float best, float* tnear)
 {
 #pragma clang fp contract(fast)
     const float a0 = lox * r2x + n2x, a1 = hix * r1x + n1x;
@@ -426,6 +429,11 @@ PT_DEV bool box_hit_cone(float lox, float loy, float loz, float hix, float hiy, 
     const float tf = fminf(fminf(fx, fy), fz);
     *tnear = tn;
     return tf >= fmaxf(tn, 0.0f) && tn <= best;
+}
+PT_DEV bool box_hit_cone(float lox, float loy, float loz, float hix, float hiy, float hiz, float r1x, float r1y, float r1z, float n1x, float n1y, float n1z,
+                         float r2x, float r2y, float r2z, float n2x, float n2y, float n2z, bool anyFlat, V3 d, float best, float* tnear)
+{
+    return cone_planes(lox, hix, loy, hiy, loz, hiz, r1x, r1y, r1z, n1x, n1y, n1z, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, d, best, tnear);
 }
 
 struct QueryCtx // per-lane scratch and counters of the sphere query
@@ -470,7 +478,7 @@ PT_DEV void trav_begin(const BvhView& b, float tLimit, int32_t planeIdx, bool li
 // stragglers keep their state (ts, LDS stack) and carry on in the next call, together with the rays the finished lanes
 // will have produced by then.  (Measured on book-1: 33 % of the inner steps and 44 % of the leaf steps of a
 // run-to-completion traversal are executed for fewer than 8 lanes.)
-template <bool MOVING, bool CONE>
+template <bool MOVING, bool CONE, bool QN>
 PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, QueryCtx& q, TravState& ts, uint32_t minActive)
 {
     const uint32_t leafBatch = q.leafBatch;
@@ -509,6 +517,13 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
         cone_axis(ray.o.x, ray.d.x, ix, nox, r2x, n2x); cone_axis(ray.o.y, ray.d.y, iy, noy, r2y, n2y); cone_axis(ray.o.z, ray.d.z, iz, noz, r2z, n2z);
     }
     const bool anyFlat = CONE && (cone_flat(ray.d.x) || cone_flat(ray.d.y) || cone_flat(ray.d.z));
+    if constexpr (QN) // fold the node grid into the per-plane pairs: (r, n) -> (step * r, org * r + n)
+    {
+        nox = b.gorg[0] * ix + nox; noy = b.gorg[1] * iy + noy; noz = b.gorg[2] * iz + noz;
+        n2x = b.gorg[0] * r2x + n2x; n2y = b.gorg[1] * r2y + n2y; n2z = b.gorg[2] * r2z + n2z;
+        ix *= b.gstep[0]; iy *= b.gstep[1]; iz *= b.gstep[2];
+        r2x *= b.gstep[0]; r2y *= b.gstep[1]; r2z *= b.gstep[2];
+    }
     // All lanes run the loops below together (their exits are wave-uniform), which keeps the two tallies in scalar registers.
     uint32_t* sp = q.stack + (ts.pk & 255u) * 64u;
     uint32_t cur = ts.cur;
@@ -533,17 +548,30 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
             q.nodeVisits += nInner;                                      // wave-level tally
             if (atInner)
             {
-                const float4 n0 = b.nodes[4 * cur], n1 = b.nodes[4 * cur + 1], n2 = b.nodes[4 * cur + 2];
-                // the two references are half of the node's last 16 bytes: an 8-byte load (from HBM the compiler would
-                // fetch all 16, and the tree-in-HBM kernel is bound by the bytes the L1 hands back per lane)
-                const float2 n3 = *reinterpret_cast<const float2*>(b.nodes + 4 * cur + 3);
-                // left box {n0.xyz .. n0.w, n1.x, n1.y}, right box {n1.z, n1.w, n2.x .. n2.yzw}
-                float nearL, nearR;
-                const bool hitL = CONE ? box_hit_cone(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearL)
-                                       : box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, cull, &nearL);
-                const bool hitR = CONE ? box_hit_cone(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearR)
-                                       : box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, cull, &nearR);
-                const uint32_t refL = __float_as_uint(n3.x), refR = __float_as_uint(n3.y);
+                bool hitL, hitR; float nearL, nearR; uint32_t refL, refR;
+                if constexpr (QN)
+                {
+                    const float4 qa = b.nodes[2 * cur], qb = b.nodes[2 * cur + 1];
+                    const uint32_t lx = __float_as_uint(qa.x), ly = __float_as_uint(qa.y), lz = __float_as_uint(qa.z);
+                    const uint32_t rx = __float_as_uint(qa.w), ry = __float_as_uint(qb.x), rz = __float_as_uint(qb.y);
+                    hitL = cone_planes((float)(lx & 0xFFFFu), (float)(lx >> 16), (float)(ly & 0xFFFFu), (float)(ly >> 16), (float)(lz & 0xFFFFu), (float)(lz >> 16),
+                                       ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearL);
+                    hitR = cone_planes((float)(rx & 0xFFFFu), (float)(rx >> 16), (float)(ry & 0xFFFFu), (float)(ry >> 16), (float)(rz & 0xFFFFu), (float)(rz >> 16),
+                                       ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearR);
+                    refL = __float_as_uint(qb.z); refR = __float_as_uint(qb.w);
+                }
+                else
+                {
+                    const float4 n0 = b.nodes[4 * cur], n1 = b.nodes[4 * cur + 1], n2 = b.nodes[4 * cur + 2];
+                    // the two references are half of the node's last 16 bytes: an 8-byte load (from HBM the compiler would fetch all 16)
+                    const float2 n3 = *reinterpret_cast<const float2*>(b.nodes + 4 * cur + 3);
+                    // left box {n0.xyz .. n0.w, n1.x, n1.y}, right box {n1.z, n1.w, n2.x .. n2.yzw}
+                    hitL = CONE ? box_hit_cone(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearL)
+                                : box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, cull, &nearL);
+                    hitR = CONE ? box_hit_cone(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearR)
+                                : box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, cull, &nearR);
+                    refL = __float_as_uint(n3.x); refR = __float_as_uint(n3.y);
+                }
                 if (hitL && hitR)
                 {
                     const bool leftFirst = nearL <= nearR;
@@ -624,7 +652,9 @@ template <bool MOVING> PT_DEV V3 trav_centre(const BvhView& b, int32_t slot, flo
 struct Hit { float t; int32_t prim; V3 point, normal; Material m; };
 
 // How the sphere query is answered.
-enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2, MODE_BVH_LDS = 3 }; // BVH: tree in HBM; BVH_LDS: tree staged in LDS
+enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2, MODE_BVH_LDS = 3, MODE_BVH_Q = 4 };
+constexpr bool mode_is_bvh(int m) { return m == MODE_BVH || m == MODE_BVH_LDS || m == MODE_BVH_Q; }
+constexpr bool mode_in_hbm(int m) { return m == MODE_BVH || m == MODE_BVH_Q; } // tree read from HBM: cone test // BVH: tree in HBM; BVH_LDS: tree staged in LDS
 
 // First half of cast_ray (main.cpp:180-216): planes linearly, then the sphere query; closest wins, planes win ties.
 // plane loop (main.cpp:186-200): closest plane hit, or kF32Max / -1
@@ -682,11 +712,11 @@ template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, cons
     uint32_t* searched = &q.searched;
     int32_t planeIdx = -1;
     const float planeT = closest_plane(s, ray, &planeIdx);
-    if (MODE == MODE_BVH || MODE == MODE_BVH_LDS)
+    if (mode_is_bvh(MODE))
     {
         TravState ts;
         trav_begin(q.bvh, planeT, planeIdx, live, q, ts);
-        bvh_run<MOVING, MODE == MODE_BVH>(q.bvh, ray, time, live, q, ts, 0u);
+        bvh_run<MOVING, mode_in_hbm(MODE), MODE == MODE_BVH_Q>(q.bvh, ray, time, live, q, ts, 0u);
         return make_hit_bvh<MOVING>(s, ray, time, q, ts);
     }
     int32_t obj;

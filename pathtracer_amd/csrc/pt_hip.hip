@@ -149,7 +149,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     float* const image = a.nchunks > 1u ? a.partial : a.out_sum;
     // BVH kernels: a lane's sphere query may span several trips (bvh_run's early exit); ts.cur != kBvhDone marks a
     // lane whose query is under way.
-    constexpr bool kBvh = RESUME && (MODE == MODE_BVH || MODE == MODE_BVH_LDS);
+    constexpr bool kBvh = RESUME && mode_is_bvh(MODE);
     TravState ts; ts.cur = kBvhDone; ts.best = 0.0f; ts.bestSlot = -1; ts.pk = 0;
   for (uint32_t unit = waveId;;)
   {
@@ -232,7 +232,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
                 const float planeT = closest_plane(s, ray, &planeIdx);
                 trav_begin(qc.bvh, planeT, planeIdx, alive, qc, ts);
             }
-            bvh_run<MOVING, MODE == MODE_BVH>(qc.bvh, ray, time, alive, qc, ts, a.sc.exit_lanes);
+            bvh_run<MOVING, mode_in_hbm(MODE), MODE == MODE_BVH_Q>(qc.bvh, ray, time, alive, qc, ts, a.sc.exit_lanes);
             ready = alive && ts.cur == kBvhDone;
             if (ready) h = make_hit_bvh<MOVING>(s, ray, time, qc, ts);
         }
@@ -293,8 +293,8 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     {
         unsigned long long* slot = a.stats + kStatWords * (1u + waveId);
         slot[0] = segs; slot[1] = iters; slot[5] = qc.searched;
-        slot[6] = (MODE == MODE_BVH || MODE == MODE_BVH_LDS) ? qc.nodeVisits : 0u; // both tallies are wave-level already
-        slot[7] = (MODE == MODE_BVH || MODE == MODE_BVH_LDS) ? qc.sphereTests : 0u;
+        slot[6] = mode_is_bvh(MODE) ? qc.nodeVisits : 0u; // both tallies are wave-level already
+        slot[7] = mode_is_bvh(MODE) ? qc.sphereTests : 0u;
 #ifdef PT_STAMPS
         slot[2] = cyc_refill; slot[3] = cyc_hit; slot[4] = cyc_shade;
         slot[9] = qc.innerIters; slot[10] = qc.leafIters; slot[11] = qc.cycInner; slot[12] = qc.cycLeaf;
@@ -351,7 +351,7 @@ using RenderKernel = void (*)(RenderArgs);
 template <bool MOVING, int MODE, bool CARRY> RenderKernel render_kernel_for(bool resume)
 {
     if constexpr (MODE == MODE_BVH_LDS) return resume ? &k_render_w7<MOVING, MODE, true, CARRY> : &k_render_w7<MOVING, MODE, false, CARRY>;
-    else if constexpr (MODE == MODE_BVH) return resume ? &k_render_w6<MOVING, MODE, true, CARRY> : &k_render_w6<MOVING, MODE, false, CARRY>;
+    else if constexpr (mode_in_hbm(MODE)) return resume ? &k_render_w6<MOVING, MODE, true, CARRY> : &k_render_w6<MOVING, MODE, false, CARRY>;
     else if constexpr (MODE == MODE_LDS_STRICT) return &k_render<MOVING, MODE, CARRY>;
     else return &k_render_w6<MOVING, MODE, false, CARRY>;
 }
@@ -359,6 +359,7 @@ template <bool MOVING, bool CARRY> RenderKernel render_kernel_mc(int mode, bool 
 {
     if (mode == MODE_BVH_LDS) return render_kernel_for<MOVING, MODE_BVH_LDS, CARRY>(resume);
     if (mode == MODE_BVH) return render_kernel_for<MOVING, MODE_BVH, CARRY>(resume);
+    if (mode == MODE_BVH_Q) return render_kernel_for<MOVING, MODE_BVH_Q, CARRY>(resume);
     if (mode == MODE_LDS_STRICT) return render_kernel_for<MOVING, MODE_LDS_STRICT, CARRY>(resume);
     return render_kernel_for<MOVING, MODE_LDS_FAST, CARRY>(resume);
 }
@@ -527,6 +528,7 @@ struct pt_ctx
     int num_cus = 0;
     unsigned long long* stats_dev = nullptr;
     uint32_t stat_slots = 0;
+    bool bvh_q = false;   // the tree in HBM is stored as 32-byte grid nodes (MODE_BVH_Q)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int last_mode = MODE_LDS_FAST;
@@ -558,6 +560,7 @@ constexpr uint32_t kMinResidentWaves = 16; // per CU: below this the LDS-residen
 // BVH traversal: bvh_run's minActive for the tree in LDS and in HBM (book-1 1080p: 105.1 -> 102.2 ms with 8, flat
 // from 6 to 12; 10^6 spheres 4K: 431 -> 594 -> 669 -> 700 Msamples/s with 0, 8, 16, 24); a single-leaf tree (up to 4 spheres) has no stragglers and skips it.
 constexpr uint32_t kExitLanes = 8, kExitLanesHbm = 24, kResumeMinSpheres = 4;
+constexpr uint32_t kGridNodeMinSpheres = 32768; // from here on the tree in HBM uses 32-byte grid nodes
 constexpr uint32_t kRefillMin = 20; // lanes that must be out of work before the wave runs the refill code (render_body)
 constexpr uint32_t kLeafBatch = 16; // BVH traversal: lanes gathered at leaves before the leaf code runs (pt_device.h, bvh_closest)
 
@@ -601,9 +604,9 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
     else
     {
         if (flags & PT_FLAG_FORCE_LDS) return PT_ERR_UNSUPPORTED;
-        *mode = MODE_BVH; *sc = &ctx->sc_bvh;
+        *mode = ctx->bvh_q ? MODE_BVH_Q : MODE_BVH; *sc = &ctx->sc_bvh;
     }
-    const size_t stack = (*mode == MODE_BVH || *mode == MODE_BVH_LDS) ? (size_t)(*sc)->stack_entries * 64 * 4 : 0;
+    const size_t stack = mode_is_bvh(*mode) ? (size_t)(*sc)->stack_entries * 64 * 4 : 0;
     *lds = (size_t)(*sc)->blob_f4 * 16 + waves * ((acc ? kAccBytesPerWave : 0) + stack);
     if (*lds > ctx->lds_limit) return PT_ERR_UNSUPPORTED;
     return PT_OK;
@@ -614,8 +617,8 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
     do {                                                                                                        \
         int st_ = PT_OK;                                                                                        \
         auto go_ = [&](auto kern) { st_ = set_lds(ctx, kern, lds); if (st_ == PT_OK) hipLaunchKernelGGL(kern, grid, block, lds, stream, args); }; \
-        if (moving) { if (mode == MODE_BVH_LDS) go_(KERNEL<true, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<true, MODE_BVH>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<true, MODE_LDS_STRICT>); else go_(KERNEL<true, MODE_LDS_FAST>); } \
-        else        { if (mode == MODE_BVH_LDS) go_(KERNEL<false, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<false, MODE_BVH>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<false, MODE_LDS_STRICT>); else go_(KERNEL<false, MODE_LDS_FAST>); } \
+        if (moving) { if (mode == MODE_BVH_LDS) go_(KERNEL<true, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<true, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<true, MODE_BVH_Q>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<true, MODE_LDS_STRICT>); else go_(KERNEL<true, MODE_LDS_FAST>); } \
+        else        { if (mode == MODE_BVH_LDS) go_(KERNEL<false, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<false, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<false, MODE_BVH_Q>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<false, MODE_LDS_STRICT>); else go_(KERNEL<false, MODE_LDS_FAST>); } \
         if (st_ != PT_OK) return st_;                                                                           \
     } while (0)
 
@@ -773,12 +776,27 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         planesOnly.n_spheres = 0;
         pth::build_blob(&planesOnly, &ctx->blob_planes);
         st = upload_f4(ctx, ctx->blob_planes.f4.data(), ctx->blob_planes.f4.size() * 16, &ctx->blob_planes_dev); if (st != PT_OK) return st;
-        st = upload_f4(ctx, bv.nodes.data(), bv.nodes.size() * 4, &ctx->nodes_dev); if (st != PT_OK) return st;
+        // Big trees are read from HBM as 32-byte grid nodes (half the loads per step: the L1 is what binds that kernel);
+        // small ones, resident in L1/L2 and bound by instruction issue, keep the 64-byte float nodes.
+        ctx->bvh_q = bv.n_spheres >= kGridNodeMinSpheres;
+        if (const char* e = getenv("PT_GRID_NODES")) ctx->bvh_q = atoi(e) != 0 && bv.n_nodes != 0; // tests / tuning experiments
+        pth::NodeGrid grid{};
+        if (ctx->bvh_q)
+        {
+            std::vector<uint32_t> qn;
+            pth::quantise_nodes(bv, &grid, &qn);
+            st = upload_f4(ctx, qn.data(), qn.size() * 4, &ctx->nodes_dev); if (st != PT_OK) return st;
+        }
+        else
+        {
+            st = upload_f4(ctx, bv.nodes.data(), bv.nodes.size() * 4, &ctx->nodes_dev); if (st != PT_OK) return st;
+        }
         st = upload_f4(ctx, bv.sph.data(), bv.sph.size() * 4, &ctx->sph_dev); if (st != PT_OK) return st;
         st = upload_f4(ctx, bv.vel.data(), bv.vel.size() * 4, &ctx->vel_dev); if (st != PT_OK) return st;
         st = upload_f4(ctx, bv.mat.data(), bv.mat.size() * 4, &ctx->mat_dev); if (st != PT_OK) return st;
         fill_scene_args(&ctx->sc_bvh, ctx->blob_planes, ctx->blob_planes_dev, d, d->n_planes);
-        ctx->sc_bvh.bvh = BvhView{ctx->nodes_dev, ctx->sph_dev, ctx->vel_dev, ctx->mat_dev, bv.root_ref, bv.n_spheres};
+        ctx->sc_bvh.bvh = BvhView{ctx->nodes_dev, ctx->sph_dev, ctx->vel_dev, ctx->mat_dev, bv.root_ref, bv.n_spheres,
+                                  {grid.org[0], grid.org[1], grid.org[2]}, {grid.step[0], grid.step[1], grid.step[2]}};
         ctx->sc_bvh.stack_entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1; // the sentinel + at most one pushed sibling per inner node of a root-to-leaf path (bv.depth of them)
         ctx->sc_bvh.leaf_batch = kLeafBatch;
         int exitEnv = -1;
@@ -813,7 +831,7 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
             ctx->sc_bvh_lds.exit_lanes = !resumable ? 0u : exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanes;
             ctx->sc_bvh_lds.blob = ctx->blob_bvh_dev; ctx->sc_bvh_lds.blob_f4 = (uint32_t)(img.size() / 4);
             for (int k = 0; k < 4; ++k) ctx->sc_bvh_lds.bvh_off[k] = off[k];
-            ctx->sc_bvh_lds.bvh = BvhView{nullptr, nullptr, nullptr, matInLds ? nullptr : ctx->mat_dev, bv.root_ref, bv.n_spheres};
+            ctx->sc_bvh_lds.bvh = BvhView{nullptr, nullptr, nullptr, matInLds ? nullptr : ctx->mat_dev, bv.root_ref, bv.n_spheres, {0, 0, 0}, {1, 1, 1}};
             ctx->sc_bvh_lds.stack_entries = entries;
         }
     }
@@ -840,7 +858,7 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     {
         st = select_mode(ctx, flags, 1, true, &mode, &sc, &lds);
         if (st != PT_OK) return st;
-        const uint32_t lo = forced ? forced : (mode == MODE_BVH ? kWavesPerBlockBvh : kWavesPerBlock), hi = forced ? forced : (mode == MODE_BVH ? kWavesPerBlockBvh : 8u);
+        const uint32_t lo = forced ? forced : (mode_in_hbm(mode) ? kWavesPerBlockBvh : kWavesPerBlock), hi = forced ? forced : (mode_in_hbm(mode) ? kWavesPerBlockBvh : 8u);
         waves = 0; wgPerCu = 0;
         for (uint32_t wv = lo; wv <= hi; wv *= 2)
         {
@@ -929,7 +947,7 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     ctx->last_mode = mode;
     ctx->last = pt_stats{};
     ctx->last.samples = (uint64_t)p->width * p->height * a.nspp;
-    ctx->last.kernel = mode == MODE_BVH ? 1u : mode == MODE_BVH_LDS ? 3u : mode == MODE_LDS_STRICT ? 2u : 0u;
+    ctx->last.kernel = mode_in_hbm(mode) ? 1u : mode == MODE_BVH_LDS ? 3u : mode == MODE_LDS_STRICT ? 2u : 0u;
     return PT_OK;
 }
 
@@ -966,7 +984,7 @@ int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out)
     ctx->last.segments = st[0];
     ctx->last.wave_iterations = st[1];
     ctx->last.phase_cycles[0] = st[2]; ctx->last.phase_cycles[1] = st[3]; ctx->last.phase_cycles[2] = st[4];
-    if (ctx->last_mode == MODE_BVH || ctx->last_mode == MODE_BVH_LDS)
+    if (mode_is_bvh(ctx->last_mode))
     {
         ctx->last.node_visits = st[6];   // inner nodes fetched (two box tests each)
         ctx->last.sphere_tests = st[7];  // exact leaf tests

@@ -151,3 +151,34 @@ def test_large_scene_reproduces_the_reference_formulas_phantom_hits(renderer, or
         phantom = any(disc <= err for disc, err in bands)
         close = prim[i] >= 0 and po_[i] >= 0 and abs(float(t[i]) - float(to[i])) <= 2e-3 * float(to[i])
         assert phantom or close, (int(i), int(prim[i]), float(t[i]), int(po_[i]), float(to[i]), bands)
+
+
+@pytest.mark.parametrize("name", ["scene2_2400", "scene1_forced", "scene3_moving_forced", "random_moving_300_forced", "tiny_3_forced"])
+def test_grid_nodes_bit_exact(renderer, oracle, monkeypatch, name):
+    """The 32-byte grid nodes that big trees in HBM use (>= 32768 spheres by default; the 10^5-sphere test below runs on
+    them) forced onto small scenes: the boxes only decide which leaves are visited, so hits, per-sample radiance and
+    rendered frames stay the oracle's, to the bit."""
+    monkeypatch.setenv("PT_GRID_NODES", "1")
+    sa, flags = SCENES[name]
+    flags |= pt.FLAG_FORCE_BVH
+    renderer.upload(to_pt_scene(sa))
+    h = oracle.scene(sa)
+    try:
+        rays, times = _rays(oracle, sa, 8192, 15)
+        t, prim, p, nr = renderer.probe_hits(rays, times, flags)
+        to, po_, pto, nro = oracle.closest_hits(h, rays, times, po.QUERY_CLOSEST)
+        assert (prim == po_).all(), (name, int((prim != po_).sum()))
+        assert bit_equal(t, to) and bit_equal(p, pto) and bit_equal(nr, nro), name
+        rng = np.random.default_rng(16)
+        w, hgt, n = 160, 90, 2000
+        pixels, samples = rng.integers(0, w * hgt, n).astype(np.uint32), rng.integers(0, 9999, n).astype(np.uint32)
+        c, segs = renderer.probe_samples(w, hgt, pixels, samples, 50, seed=18, flags=flags)
+        co, segso = oracle.samples_philox(h, w, hgt, pixels, samples, 50, seed=18)
+        assert (segs == segso).all() and bit_equal(c, co), name
+        img = renderer.render(96, 54, 0, 12, 50, seed=19, flags=flags)
+        st = renderer.stats()
+        ref, seg = oracle.render_philox(h, 96, 54, 0, 12, 50, seed=19)
+        assert st["kernel"] == 1 and st["segments"] == seg, name
+        assert np.abs(img.astype(np.float64) - ref.astype(np.float64)).max() <= 2 * 12 * 2.0 ** -24 * max(1.0, float(np.abs(ref).max()))
+    finally:
+        oracle.scene_free(h)

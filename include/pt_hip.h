@@ -71,6 +71,7 @@ typedef struct pt_params {
 
 /* How the closest-sphere query is answered (all give the same definition of the answer):
  *   default            : BVH traversal with the tree staged in LDS when it fits (book-1 scene: 18 KB), else from HBM
+ *                        (from 32768 spheres up as 32-byte nodes on a 16-bit grid; leaf tests stay exact)
  *   PT_FLAG_BRUTE_FORCE: two-level brute force over the LDS-resident SoA scene in packed FP32 (the FP32-VALU-bound
  *                        formulation of BASELINE.json's north star; approximate search + exact re-evaluation)
  *   PT_FLAG_STRICT_SEARCH: brute force in reference arithmetic for every sphere (slow; parity tests)

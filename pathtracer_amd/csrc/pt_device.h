@@ -128,6 +128,10 @@ struct TapeRng
 };
 
 template <class R> PT_DEV float rand_range(R& r, float lo, float hi) { return r.f32() * (hi - lo) + lo; } // utils.h:47-51
+// rand_range(r, -1, 1) = u * 2 - 1 with u = k * 2^-24: both scalings are by powers of two, hence exact, and k * 2^-23 - 1
+// is the same float one multiply sooner (the rejection loops draw nothing else).
+template <class R> PT_DEV float rand_pm1(R& r) { return rand_range(r, -1.0f, 1.0f); }
+PT_DEV float rand_pm1(PhiloxRng& r) { return (float)(r.word() >> 8) * 1.1920928955078125e-7f - 1.0f; }
 
 // ------------------------------------------------------------------ samplers (utils.h:71-138)
 // Draw order z,y,x / y,x: what g++ makes of the reference's unspecified argument order.
@@ -141,7 +145,7 @@ template <class R> PT_DEV V3 random_point_in_unit_sphere(R& r)               // 
     V3 p;
     for (;;)
     {
-        float z = rand_range(r, -1.0f, 1.0f), y = rand_range(r, -1.0f, 1.0f), x = rand_range(r, -1.0f, 1.0f);
+        float z = rand_pm1(r), y = rand_pm1(r), x = rand_pm1(r);
         p = v3(x, y, z);
         if (norm_squared(p) <= kOnePlusUlp) break;                       // == (norm(p) <= 1.0f), see above
     }
@@ -153,7 +157,7 @@ template <class R> PT_DEV V3 random_point_in_unit_circle(R& r)               // 
     V3 p;
     for (;;)
     {
-        float y = rand_range(r, -1.0f, 1.0f), x = rand_range(r, -1.0f, 1.0f);
+        float y = rand_pm1(r), x = rand_pm1(r);
         p = v3(x, y, 0.0f);
         if (norm_squared(p) <= kOnePlusUlp) break;                       // == (norm(p) <= 1.0f), see above
     }

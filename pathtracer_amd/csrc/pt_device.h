@@ -128,10 +128,11 @@ struct TapeRng
 };
 
 template <class R> PT_DEV float rand_range(R& r, float lo, float hi) { return r.f32() * (hi - lo) + lo; } // utils.h:47-51
-// rand_range(r, -1, 1) = u * 2 - 1 with u = k * 2^-24: both scalings are by powers of two, hence exact, and k * 2^-23 - 1
-// is the same float one multiply sooner (the rejection loops draw nothing else).
+// rand_range(r, -1, 1) = u * 2 - 1 with u = k * 2^-24: both scalings are by powers of two, hence exact, so k * 2^-23 - 1
+// is the same float -- and as the product is exact, one FMA rounds exactly like the multiply-then-add (the rejection
+// loops draw nothing else: two instructions less per draw).
 template <class R> PT_DEV float rand_pm1(R& r) { return rand_range(r, -1.0f, 1.0f); }
-PT_DEV float rand_pm1(PhiloxRng& r) { return (float)(r.word() >> 8) * 1.1920928955078125e-7f - 1.0f; }
+PT_DEV float rand_pm1(PhiloxRng& r) { return __builtin_fmaf((float)(r.word() >> 8), 1.1920928955078125e-7f, -1.0f); }
 
 // ------------------------------------------------------------------ samplers (utils.h:71-138)
 // Draw order z,y,x / y,x: what g++ makes of the reference's unspecified argument order.

@@ -623,7 +623,7 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
     } while (0)
 
 constexpr uint64_t kGuide = 48;        // guided schedule: a unit is at most 1/kGuide of a resident wave's even share of what is left (tile cost varies ~10x: measured optimum 32-64)
-constexpr uint32_t kMinChunkSpp = 8;   // never cut a tile's samples finer than this (the drain at the end of a unit idles lanes)
+constexpr uint32_t kMinChunkSpp = 8;   // never cut a tile's samples finer than this (every unit has fixed costs; measured: 4 and 16 are no better)
 constexpr uint32_t kMaxChunks = 4096;  // (the walk in the kernel is linear in the chunk index)
 constexpr uint64_t kMaxPartialBytes = 4ull << 30; // per-chunk partial images the context may hold
 

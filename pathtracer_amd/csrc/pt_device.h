@@ -81,18 +81,24 @@ struct PhiloxRng
 {
     uint32_t k0, k1, pixel, sample, k;
     uint32_t b0, b1, b2, b3; // words k, k+1, .. of the current block, shifted down as they are consumed
+    bool primed;             // the block of word k (k on a block boundary) is already in b0..b3
     PT_DEV void init(uint64_t seed, uint32_t px, uint32_t smp)
     {
         k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32); pixel = px; sample = smp; k = 0;
-        b0 = b1 = b2 = b3 = 0;
+        b0 = b1 = b2 = b3 = 0; primed = false;
+    }
+    PT_DEV void fill()
+    {
+        uint32_t o[4];
+        philox4x32_10(k >> 2, pixel, sample, 0u, k0, k1, o);
+        b0 = o[0]; b1 = o[1]; b2 = o[2]; b3 = o[3];
     }
     PT_DEV uint32_t word()
     {
         if ((k & 3u) == 0u)
         {
-            uint32_t o[4];
-            philox4x32_10(k >> 2, pixel, sample, 0u, k0, k1, o);
-            b0 = o[0]; b1 = o[1]; b2 = o[2]; b3 = o[3];
+            if (!primed) fill();
+            primed = false;
         }
         uint32_t w = b0;
         b0 = b1; b1 = b2; b2 = b3;
@@ -109,9 +115,13 @@ struct PhiloxRng
     // draw counts, and without this each of the 3 draws of a rejection attempt refills for SOME lane (three Philox
     // evaluations per attempt instead of 3/4).  Part of the stream's definition (DESIGN.md "RNG"); the oracle does the same.
     PT_DEV void align() { k = (k + 3u) & ~3u; }
+    // Behind align(): evaluate the block now, for every lane that is here.  The draws that follow come from different
+    // branches -- the glass lanes' f64, the first attempt of the other lanes' rejection loop -- and each would evaluate
+    // the same block of its own lanes' streams in its own copy of the ten rounds, one after the other.
+    PT_DEV void prime() { fill(); primed = true; }
     // align() + forget the rest of the block: the next draw refills anyway, and the four words stop being live state
     // (registers) across whatever comes in between -- the whole sphere query, in the render loop.
-    PT_DEV void park() { align(); b0 = b1 = b2 = b3 = 0; }
+    PT_DEV void park() { align(); b0 = b1 = b2 = b3 = 0; primed = false; }
     PT_DEV bool overrun() const { return false; }
 };
 
@@ -123,6 +133,7 @@ struct TapeRng
     PT_DEV float f32() { if (i32 >= n32) { over = true; ++i32; return 0.5f; } return t32[i32++]; }
     PT_DEV double f64() { if (i64 >= n64) { over = true; ++i64; return 0.5; } return t64[i64++]; }
     PT_DEV void align() {}
+    PT_DEV void prime() {}
     PT_DEV void park() {}
     PT_DEV bool overrun() const { return over; }
 };
@@ -794,6 +805,7 @@ template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray
     *event = EV_SCATTER;
     out->o = h.point;
     rng.align();
+    rng.prime();
     // The dielectric's single f64 draw (main.cpp:276) is taken here, right behind align(): its two words are then
     // words 0,1 of a fresh block, one Philox evaluation, known at compile time.
     const double xi = (h.m.type == MAT_DIALECTRIC) ? rng.f64() : 0.0;

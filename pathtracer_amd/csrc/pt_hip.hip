@@ -135,7 +135,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     // cursor only grows.
     // (A wave's first unit is its own index -- no 7000 atomics on one address at the start of the launch; the cursor
     // hands out the units behind those.)
-  const uint32_t waveId = pt_uniform(blockIdx.x * nwaves + wave), cursorBase = gridDim.x * nwaves;
+    const uint32_t waveId = pt_uniform(blockIdx.x * nwaves + wave), cursorBase = gridDim.x * nwaves;
     // Per-lane path state.  It outlives the unit: when a unit's pool runs dry the paths still under way are CARRIED into
     // the next unit's trips (no drain with a handful of lanes); such a path adds its result straight to its own unit's
     // pixel in HBM (kCarried | pixel index in p) instead of the tile accumulator, which by then belongs to the next unit.
@@ -151,140 +151,140 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     // lane whose query is under way.
     constexpr bool kBvh = RESUME && mode_is_bvh(MODE);
     TravState ts; ts.cur = kBvhDone; ts.best = 0.0f; ts.bestSlot = -1; ts.pk = 0;
-  for (uint32_t unit = waveId;;)
-  {
-    const bool haveUnit = unit < a.nunits;     // false: the launch's last trips, carried paths only
-    if (!haveUnit && pt_ballot(alive) == 0ull) break;
-    const uint32_t chunk = haveUnit ? unit / a.ntiles : 0u, slot = unit - chunk * a.ntiles;
-    // Neighbouring tiles cost alike (sky rows are cheap, the sphere field is not): a multiplicative shuffle of the
-    // tile order mixes cheap and expensive tiles over the whole launch.
-    const uint32_t tile = haveUnit ? (uint32_t)(((unsigned long long)slot * a.tile_stride) % a.ntiles) : 0u;
-    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    uint32_t s0 = 0, s1 = 0; // samples [s0, s1) of the call: walk the schedule up to this chunk (scalar work, once per unit)
-    if (haveUnit)
-        for (uint32_t c = 0;; ++c)
-        {
-            s1 = s0 + chunk_size(a.nspp - s0, a.chunk_ratio_q16, a.chunk_min);
-            if (c == chunk) break;
-            s0 = s1;
-        }
-    acc[lane] = 0.0f; acc[lane + 64] = 0.0f; acc[lane + 128] = 0.0f; acc[lane + 192] = 0.0f;
-
-    const uint32_t total = 64u * (s1 - s0); // work items of this unit: item i = (pixel i&63 of the tile, sample s0 + (i>>6))
-    uint32_t next = 0;                      // wave-uniform cursor into the pool
-    bool retired = false;
-
-    for (;;)
+    for (uint32_t unit = waveId;;)
     {
-        PT_STAMP(ts0);
-        // ---- refill: every lane without a live path takes the next work item (main.cpp:347-354)
-        const bool want = !alive && !retired;
-        const unsigned long long need = pt_ballot(want);
-        if (need && ((uint32_t)__popcll(need) >= a.sc.refill_min || next >= total || pt_ballot(alive) == 0ull))
-        {
-            if (want)
+        const bool haveUnit = unit < a.nunits;     // false: the launch's last trips, carried paths only
+        if (!haveUnit && pt_ballot(alive) == 0ull) break;
+        const uint32_t chunk = haveUnit ? unit / a.ntiles : 0u, slot = unit - chunk * a.ntiles;
+        // Neighbouring tiles cost alike (sky rows are cheap, the sphere field is not): a multiplicative shuffle of the
+        // tile order mixes cheap and expensive tiles over the whole launch.
+        const uint32_t tile = haveUnit ? (uint32_t)(((unsigned long long)slot * a.tile_stride) % a.ntiles) : 0u;
+        const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+        uint32_t s0 = 0, s1 = 0; // samples [s0, s1) of the call: walk the schedule up to this chunk (scalar work, once per unit)
+        if (haveUnit)
+            for (uint32_t c = 0;; ++c)
             {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                const uint32_t item = next + rank;
-                if (item < total)
+                s1 = s0 + chunk_size(a.nspp - s0, a.chunk_ratio_q16, a.chunk_min);
+                if (c == chunk) break;
+                s0 = s1;
+            }
+        acc[lane] = 0.0f; acc[lane + 64] = 0.0f; acc[lane + 128] = 0.0f; acc[lane + 192] = 0.0f;
+
+        const uint32_t total = 64u * (s1 - s0); // work items of this unit: item i = (pixel i&63 of the tile, sample s0 + (i>>6))
+        uint32_t next = 0;                      // wave-uniform cursor into the pool
+        bool retired = false;
+
+        for (;;)
+        {
+            PT_STAMP(ts0);
+            // ---- refill: every lane without a live path takes the next work item (main.cpp:347-354)
+            const bool want = !alive && !retired;
+            const unsigned long long need = pt_ballot(want);
+            if (need && ((uint32_t)__popcll(need) >= a.sc.refill_min || next >= total || pt_ballot(alive) == 0ull))
+            {
+                if (want)
                 {
-                    p = item & 63u;
-                    const uint32_t px = tx * 8u + (p & 7u), py = ty * 8u + (p >> 3);
-                    if (px < a.width && py < a.height) // ragged edge tiles: the item is skipped
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                    const uint32_t item = next + rank;
+                    if (item < total)
                     {
-                        rng.init(a.seed, py * a.width + px, a.spp_begin + s0 + (item >> 6));
-                        const Ray r0 = begin_sample(*reinterpret_cast<const DeviceCamera*>(smem + a.sc.off_cam), px, py, a.width, a.height, a.sc.t0, a.sc.t1, rng, &time);
-                        rox = r0.o.x; roy = r0.o.y; roz = r0.o.z; rdx = r0.d.x; rdy = r0.d.y; rdz = r0.d.z;
-                        T = v4(1, 1, 1, 1);
-                        depth = a.max_depth;
-                        alive = depth != 0;
-                        if (!alive) atomicAdd(&acc[p * 4u + 3u], 1.0f); // maxDepth 0 -> BLACK (0,0,0,1) (main.cpp:175-176)
+                        p = item & 63u;
+                        const uint32_t px = tx * 8u + (p & 7u), py = ty * 8u + (p >> 3);
+                        if (px < a.width && py < a.height) // ragged edge tiles: the item is skipped
+                        {
+                            rng.init(a.seed, py * a.width + px, a.spp_begin + s0 + (item >> 6));
+                            const Ray r0 = begin_sample(*reinterpret_cast<const DeviceCamera*>(smem + a.sc.off_cam), px, py, a.width, a.height, a.sc.t0, a.sc.t1, rng, &time);
+                            rox = r0.o.x; roy = r0.o.y; roz = r0.o.z; rdx = r0.d.x; rdy = r0.d.y; rdz = r0.d.z;
+                            T = v4(1, 1, 1, 1);
+                            depth = a.max_depth;
+                            alive = depth != 0;
+                            if (!alive) atomicAdd(&acc[p * 4u + 3u], 1.0f); // maxDepth 0 -> BLACK (0,0,0,1) (main.cpp:175-176)
+                        }
                     }
+                    else
+                        retired = true;
                 }
-                else
-                    retired = true;
+                next += (uint32_t)__popcll(need);
             }
-            next += (uint32_t)__popcll(need);
-        }
-        if (CARRY && haveUnit && next >= total)
-        {
-            // The pool is empty: whoever is still under way is carried (its tile pixel becomes an index into the image).
-            if (alive && !(p & kCarried))
-                p = kCarried | (chunk * (a.width * a.height) + (ty * 8u + (p >> 3)) * a.width + tx * 8u + (p & 7u));
-            break;
-        }
-        if (pt_ballot(alive) == 0ull)
-        {
-            if (CARRY ? !haveUnit : next >= total) break;
-            continue;
-        }
-        // ---- one segment for every lane (lanes without a live path ride along on stale data)
-        ++iters;
-        PT_STAMP(ts1);
-        Ray ray; ray.o = v3(rox, roy, roz); ray.d = v3(rdx, rdy, rdz);
-        Hit h;
-        bool ready = alive;
-        if constexpr (kBvh)
-        {
-            if (ts.cur == kBvhDone) // a new segment: planes first, then the tree from its root (a lane without a path parks on the sentinel)
+            if (CARRY && haveUnit && next >= total)
             {
-                int32_t planeIdx = -1;
-                const float planeT = closest_plane(s, ray, &planeIdx);
-                trav_begin(qc.bvh, planeT, planeIdx, alive, qc, ts);
+                // The pool is empty: whoever is still under way is carried (its tile pixel becomes an index into the image).
+                if (alive && !(p & kCarried))
+                    p = kCarried | (chunk * (a.width * a.height) + (ty * 8u + (p >> 3)) * a.width + tx * 8u + (p & 7u));
+                break;
             }
-            bvh_run<MOVING, mode_in_hbm(MODE), MODE == MODE_BVH_Q>(qc.bvh, ray, time, alive, qc, ts, a.sc.exit_lanes);
-            ready = alive && ts.cur == kBvhDone;
-            if (ready) h = make_hit_bvh<MOVING>(s, ray, time, qc, ts);
-        }
-        else
-            h = closest_hit<MOVING, MODE>(s, ray, time, alive, qc);
-        PT_STAMP(ts2);
-        if (ready)
-        {
-            ++segs;
-            V4 terminal;
-            const bool goes_on = shade_step(ray, h, T, rng, &terminal);
-            rng.park(); // the next scatter aligns to a fresh block anyway: drop the buffered words from the live state
-            rox = ray.o.x; roy = ray.o.y; roz = ray.o.z; rdx = ray.d.x; rdy = ray.d.y; rdz = ray.d.z;
-            bool ended = !goes_on;
-            if (goes_on && --depth == 0) { terminal = v4(0, 0, 0, 1); ended = true; } // main.cpp:175-176
-            if (ended)
+            if (pt_ballot(alive) == 0ull)
             {
-                const V4 c = hadamard(T, terminal);
-                if (p & kCarried)
-                {
-                    float* dst = image + 4u * (size_t)(p & ~kCarried);
-                    unsafeAtomicAdd(dst, c.x); unsafeAtomicAdd(dst + 1, c.y); unsafeAtomicAdd(dst + 2, c.z); unsafeAtomicAdd(dst + 3, c.w);
-                }
-                else
-                {
-                    atomicAdd(&acc[p * 4u + 0u], c.x); atomicAdd(&acc[p * 4u + 1u], c.y);
-                    atomicAdd(&acc[p * 4u + 2u], c.z); atomicAdd(&acc[p * 4u + 3u], c.w);
-                }
-                alive = false;
+                if (CARRY ? !haveUnit : next >= total) break;
+                continue;
             }
-        }
+            // ---- one segment for every lane (lanes without a live path ride along on stale data)
+            ++iters;
+            PT_STAMP(ts1);
+            Ray ray; ray.o = v3(rox, roy, roz); ray.d = v3(rdx, rdy, rdz);
+            Hit h;
+            bool ready = alive;
+            if constexpr (kBvh)
+            {
+                if (ts.cur == kBvhDone) // a new segment: planes first, then the tree from its root (a lane without a path parks on the sentinel)
+                {
+                    int32_t planeIdx = -1;
+                    const float planeT = closest_plane(s, ray, &planeIdx);
+                    trav_begin(qc.bvh, planeT, planeIdx, alive, qc, ts);
+                }
+                bvh_run<MOVING, mode_in_hbm(MODE), MODE == MODE_BVH_Q>(qc.bvh, ray, time, alive, qc, ts, a.sc.exit_lanes);
+                ready = alive && ts.cur == kBvhDone;
+                if (ready) h = make_hit_bvh<MOVING>(s, ray, time, qc, ts);
+            }
+            else
+                h = closest_hit<MOVING, MODE>(s, ray, time, alive, qc);
+            PT_STAMP(ts2);
+            if (ready)
+            {
+                ++segs;
+                V4 terminal;
+                const bool goes_on = shade_step(ray, h, T, rng, &terminal);
+                rng.park(); // the next scatter aligns to a fresh block anyway: drop the buffered words from the live state
+                rox = ray.o.x; roy = ray.o.y; roz = ray.o.z; rdx = ray.d.x; rdy = ray.d.y; rdz = ray.d.z;
+                bool ended = !goes_on;
+                if (goes_on && --depth == 0) { terminal = v4(0, 0, 0, 1); ended = true; } // main.cpp:175-176
+                if (ended)
+                {
+                    const V4 c = hadamard(T, terminal);
+                    if (p & kCarried)
+                    {
+                        float* dst = image + 4u * (size_t)(p & ~kCarried);
+                        unsafeAtomicAdd(dst, c.x); unsafeAtomicAdd(dst + 1, c.y); unsafeAtomicAdd(dst + 2, c.z); unsafeAtomicAdd(dst + 3, c.w);
+                    }
+                    else
+                    {
+                        atomicAdd(&acc[p * 4u + 0u], c.x); atomicAdd(&acc[p * 4u + 1u], c.y);
+                        atomicAdd(&acc[p * 4u + 2u], c.z); atomicAdd(&acc[p * 4u + 3u], c.w);
+                    }
+                    alive = false;
+                }
+            }
 #ifdef PT_STAMPS
-        PT_STAMP(ts3);
-        cyc_refill += ts1 - ts0; cyc_hit += ts2 - ts1; cyc_shade += ts3 - ts2;
+            PT_STAMP(ts3);
+            cyc_refill += ts1 - ts0; cyc_hit += ts2 - ts1; cyc_shade += ts3 - ts2;
 #endif
-    }
-
-    // ---- one 16-byte store per pixel and unit (plus the carried paths' atomics: the only HBM traffic of the render
-    // besides staging the scene).  The store must have landed before a carried path of this unit adds to it.
-    if (haveUnit)
-    {
-        const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
-        if (px < a.width && py < a.height)
-        {
-            float4 v = make_float4(acc[lane * 4u], acc[lane * 4u + 1u], acc[lane * 4u + 2u], acc[lane * 4u + 3u]);
-            reinterpret_cast<float4*>(image)[(size_t)chunk * a.width * a.height + (size_t)py * a.width + px] = v;
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-        if (lane == 0) unit = cursorBase + atomicAdd(reinterpret_cast<unsigned int*>(a.stats + 8), 1u);
-        unit = pt_uniform(unit);
-    }
-  } // units
+
+        // ---- one 16-byte store per pixel and unit (plus the carried paths' atomics: the only HBM traffic of the render
+        // besides staging the scene).  The store must have landed before a carried path of this unit adds to it.
+        if (haveUnit)
+        {
+            const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
+            if (px < a.width && py < a.height)
+            {
+                float4 v = make_float4(acc[lane * 4u], acc[lane * 4u + 1u], acc[lane * 4u + 2u], acc[lane * 4u + 3u]);
+                reinterpret_cast<float4*>(image)[(size_t)chunk * a.width * a.height + (size_t)py * a.width + px] = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+            if (lane == 0) unit = cursorBase + atomicAdd(reinterpret_cast<unsigned int*>(a.stats + 8), 1u);
+            unit = pt_uniform(unit);
+        }
+    } // units
     // ---- statistics: every wave leaves its tallies in a slot of its own (plain stores; k_sum_stats adds the slots up).
     // Atomics on shared counters would be ~36 000 same-address operations in the launch's last microseconds: measured,
     // they were 0.7 ms -- the whole fixed cost of a small launch.

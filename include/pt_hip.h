@@ -133,6 +133,14 @@ int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out);
  * sizes sum to nspp.  Exposed so that the schedule the kernels walk can be checked without a GPU. */
 uint32_t pt_chunk_schedule(uint32_t nspp, uint32_t ratio_q16, uint32_t min_spp, uint32_t* out_sizes, uint32_t cap);
 
+/* Host-only helper (no reference counterpart; touches no device): builds the BVH pt_hip_upload_scene would build for
+ * `scene`, in both node formats, and checks what the parity argument rests on -- every sphere's swept box inside the
+ * box of its leaf, every leaf reachable exactly once, every 32-byte grid node enclosing the 64-byte node it encodes.
+ * out8: [0] nodes [1] depth [2] leaves [3] largest leaf [4] spheres found in leaves [5] spheres outside their leaf box
+ * [6] grid boxes that fail to enclose their float box [7] references out of range.  Returns PT_OK when [4] equals the
+ * sphere count and [5..7] are zero, PT_ERR_INVALID otherwise. */
+int pt_bvh_selfcheck(const pt_scene_desc* scene, uint64_t out8[8]);
+
 /* Diagnostics (no reference counterpart): the raw device counter words of the last render, for the tuning tools under
  * tools/.  [0] segments [1] wave iterations [2..4] phase cycles [5] groups searched [6] node visits [7] sphere tests
  * [8] units handed out [9] wave-level inner-step trips [10] wave-level leaf-step trips [11..12] their cycles (stamps build). */

@@ -22,7 +22,7 @@ PRIM_MISS = -(2 ** 31)
 # Every symbol include/pt_hip.h declares (tests/test_abi.py checks the library exports exactly these).
 EXPORTS = (
     "pt_hip_device_count", "pt_hip_create", "pt_hip_destroy", "pt_hip_strerror", "pt_hip_last_error",
-    "pt_hip_upload_scene", "pt_hip_render", "pt_hip_render_device", "pt_hip_last_stats", "pt_hip_debug_counters", "pt_chunk_schedule", "pt_hip_resolve_device",
+    "pt_hip_upload_scene", "pt_hip_render", "pt_hip_render_device", "pt_hip_last_stats", "pt_hip_debug_counters", "pt_chunk_schedule", "pt_bvh_selfcheck", "pt_hip_resolve_device",
     "pt_resolve", "pt_pack_bgra", "pt_bmp_write", "pt_bmp_write_bgra", "pt_bmp_header",
     "pt_scene_builtin", "pt_scene_get_desc", "pt_scene_free", "pt_scene_save", "pt_scene_load",
     "pt_hip_probe_primitives", "pt_hip_probe_hits", "pt_hip_probe_get_rays", "pt_hip_probe_scatter", "pt_hip_probe_paths",
@@ -96,6 +96,8 @@ def load_library(path=LIB_PATH):
     L.pt_hip_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 16)]
     L.pt_chunk_schedule.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]
     L.pt_chunk_schedule.restype = C.c_uint32
+    L.pt_bvh_selfcheck.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.pt_bvh_selfcheck.restype = C.c_int
     L.pt_hip_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
@@ -191,6 +193,14 @@ class Scene:
     def load(path):
         """A scene file written by save() / pt_scene_save (text; format in pathtracer_amd/host/pt_world.cpp)."""
         return Scene._from_handle(load_library().pt_scene_load(os.fsencode(path)), f"pt_scene_load({path})")
+
+    def bvh_selfcheck(self):
+        """Host-only: build this scene's BVH in both node formats and check its invariants (include/pt_hip.h).
+        Returns (status, dict of the eight counters)."""
+        out = (C.c_uint64 * 8)()
+        st = load_library().pt_bvh_selfcheck(C.byref(self.desc), out)
+        keys = ("nodes", "depth", "leaves", "largest_leaf", "spheres_in_leaves", "spheres_outside_leaf_box", "grid_boxes_not_enclosing", "bad_references")
+        return st, dict(zip(keys, (int(v) for v in out)))
 
     def save(self, path):
         st = load_library().pt_scene_save(C.byref(self.desc), os.fsencode(path))

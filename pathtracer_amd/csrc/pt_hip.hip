@@ -1011,6 +1011,70 @@ uint32_t pt_chunk_schedule(uint32_t nspp, uint32_t ratio_q16, uint32_t min_spp, 
     return n;
 }
 
+int pt_bvh_selfcheck(const pt_scene_desc* d, uint64_t out8[8])
+{
+    if (!d || !out8) return PT_ERR_INVALID;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    pth::BvhData bv;
+    pth::build_bvh(d, &bv);
+    pth::NodeGrid grid{};
+    std::vector<uint32_t> qn;
+    pth::quantise_nodes(bv, &grid, &qn);
+    out8[0] = bv.n_nodes; out8[1] = bv.depth;
+    const bool moving = bv.moving;
+    // a sphere (slot order) against a box: its swept extent t0..t1, unpadded -- the builder's padding only adds room
+    auto sphere_inside = [&](uint32_t slot, const float* lo, const float* hi) {
+        const float* sp = bv.sph.data() + 4 * (size_t)slot;
+        const float r = sqrtf(sp[3]);
+        for (int k = 0; k < 3; ++k)
+        {
+            float a = sp[k], b2 = sp[k];
+            if (moving) { const float v = bv.vel[4 * (size_t)slot + k]; a = sp[k] + v * d->t0; b2 = sp[k] + v * d->t1; }
+            if (std::min(a, b2) - r < lo[k] || std::max(a, b2) + r > hi[k]) return false;
+        }
+        return true;
+    };
+    auto visit_leaf = [&](uint32_t ref, const float* lo, const float* hi) {
+        const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 7u) + 1u;
+        ++out8[2];
+        if (count > out8[3]) out8[3] = count;
+        if ((uint64_t)first + count > bv.n_spheres) { ++out8[7]; return; }
+        for (uint32_t i = 0; i < count; ++i) { ++out8[4]; if (lo && !sphere_inside(first + i, lo, hi)) ++out8[5]; }
+    };
+    if (bv.n_spheres != 0)
+    {
+        if (bv.n_nodes == 0) visit_leaf(bv.root_ref, nullptr, nullptr);
+        else
+        {
+            std::vector<uint32_t> stack{bv.root_ref};
+            std::vector<char> seen(bv.n_nodes, 0);
+            while (!stack.empty())
+            {
+                const uint32_t node = stack.back(); stack.pop_back();
+                if (node >= bv.n_nodes || seen[node]) { ++out8[7]; continue; }
+                seen[node] = 1;
+                const float* nd = bv.nodes.data() + 16 * (size_t)node;
+                const uint32_t* q = qn.data() + 8 * (size_t)node;
+                for (int side = 0; side < 2; ++side)
+                {
+                    const float* lo = nd + 6 * side; const float* hi = nd + 6 * side + 3;
+                    for (int k = 0; k < 3; ++k) // the grid box, decoded exactly, must enclose the float box
+                    {
+                        const uint32_t w = q[3 * side + k];
+                        const double glo = (double)grid.org[k] + (double)(w & 0xFFFFu) * (double)grid.step[k];
+                        const double ghi = (double)grid.org[k] + (double)(w >> 16) * (double)grid.step[k];
+                        if (glo > (double)lo[k] || ghi < (double)hi[k]) ++out8[6];
+                    }
+                    const uint32_t ref = pth::f2u(nd[12 + side]);
+                    if (ref != q[6 + side]) ++out8[7];
+                    if (ref & pth::kLeafFlag) visit_leaf(ref, lo, hi); else stack.push_back(ref);
+                }
+            }
+        }
+    }
+    return (out8[4] == bv.n_spheres && out8[5] == 0 && out8[6] == 0 && out8[7] == 0) ? PT_OK : PT_ERR_INVALID;
+}
+
 int pt_hip_debug_counters(pt_ctx* ctx, uint64_t out16[16])
 {
     if (!ctx || !out16) return PT_ERR_INVALID;

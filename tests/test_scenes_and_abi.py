@@ -115,6 +115,31 @@ def test_product_never_touches_the_oracle():
     assert "oracle" not in needed and "ptref" not in needed
 
 
+@pytest.mark.parametrize("what", ["scene1", "scene2", "scene3_moving", "materials", "random_3", "random_5000", "random_120000", "random_moving_400", "empty"])
+def test_bvh_builder_invariants_on_the_host(what):
+    """What the closest-hit parity rests on, checked without a GPU (pt_bvh_selfcheck): every sphere sits in exactly one
+    leaf and inside that leaf's box (swept over the shutter interval for moving spheres), references stay in range, and
+    the 32-byte grid nodes big trees use enclose the float boxes they encode -- also for the multi-threaded build."""
+    from tests import _gen
+    from tests._util import to_pt_scene
+    rng = np.random.default_rng(31)
+    if what == "scene1": sc = pt.Scene.builtin(1, 16 / 9)
+    elif what == "scene2": sc = pt.Scene.builtin(2, 16 / 9)
+    elif what == "scene3_moving": sc = pt.Scene.builtin(3, 16 / 9)
+    elif what == "materials": sc = pt.Scene.builtin(4, 16 / 9)
+    elif what == "random_3": sc = to_pt_scene(_gen.random_scene(rng, 3, n_planes=1))
+    elif what == "random_5000": sc = pt.Scene.builtin(5, 16 / 9, 5000)
+    elif what == "random_120000": sc = pt.Scene.builtin(5, 16 / 9, 120000)     # above the builder's threading threshold
+    elif what == "random_moving_400": sc = to_pt_scene(_gen.random_scene(rng, 400, n_planes=2, moving=True, extent=14.0))
+    else: sc = to_pt_scene(_gen.random_scene(rng, 0, n_planes=2))
+    st, c = sc.bvh_selfcheck()
+    assert st == pt.PT_OK, c
+    assert c["spheres_in_leaves"] == sc.n_spheres and c["largest_leaf"] <= 4
+    assert c["spheres_outside_leaf_box"] == c["grid_boxes_not_enclosing"] == c["bad_references"] == 0
+    if sc.n_spheres > 4:
+        assert c["nodes"] >= (sc.n_spheres + 3) // 4 - 1 and c["depth"] < 64
+
+
 def test_chunk_schedule_partitions_the_sample_range():
     """The guided schedule the render kernel walks (host-only helper): sizes sum to nspp, respect the minimum (a last
     remainder below 2 x min goes in one piece), never exceed half of what is left, and shrink monotonically."""

@@ -561,7 +561,9 @@ constexpr uint32_t kMinResidentWaves = 16; // per CU: below this the LDS-residen
 // from 6 to 12; 10^6 spheres 4K: 431 -> 594 -> 669 -> 700 Msamples/s with 0, 8, 16, 24); a single-leaf tree (up to 4 spheres) has no stragglers and skips it.
 constexpr uint32_t kExitLanes = 8, kExitLanesHbm = 24, kResumeMinSpheres = 4;
 constexpr uint32_t kGridNodeMinSpheres = 32768; // from here on the tree in HBM uses 32-byte grid nodes
-constexpr uint32_t kRefillMin = 20; // lanes that must be out of work before the wave runs the refill code (render_body)
+// Lanes that must be out of work before the wave runs the refill code (render_body).  Scene in LDS: flat from 20 to 36 on
+// book-1, +2-4 % at 28-36 on the small scenes; tree in HBM (trips dear, refill cheap by comparison): 12.
+constexpr uint32_t kRefillMin = 28, kRefillMinHbm = 12;
 constexpr uint32_t kLeafBatch = 16; // BVH traversal: lanes gathered at leaves before the leaf code runs (pt_device.h, bvh_closest)
 
 uint32_t pick_stride(uint32_t ntiles)
@@ -804,6 +806,8 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         const bool resumable = bv.n_spheres > kResumeMinSpheres;
 
         ctx->sc_bvh.exit_lanes = !resumable ? 0u : exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanesHbm;
+        const uint32_t refillLds = ctx->sc_bvh.refill_min; // (fill_scene_args: the default, or PT_REFILL_MIN)
+        if (!getenv("PT_REFILL_MIN")) ctx->sc_bvh.refill_min = kRefillMinHbm;
         if (const char* e = getenv("PT_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->sc_bvh.leaf_batch = (uint32_t)v; } // tuning experiments only
         ctx->bvh_nodes = bv.n_nodes; ctx->bvh_depth = bv.depth;
         ctx->moving = bv.moving;
@@ -829,6 +833,7 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
             st = upload_f4(ctx, img.data(), img.size() * 4, &ctx->blob_bvh_dev); if (st != PT_OK) return st;
             ctx->sc_bvh_lds = ctx->sc_bvh;
             ctx->sc_bvh_lds.exit_lanes = !resumable ? 0u : exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanes;
+            ctx->sc_bvh_lds.refill_min = refillLds;
             ctx->sc_bvh_lds.blob = ctx->blob_bvh_dev; ctx->sc_bvh_lds.blob_f4 = (uint32_t)(img.size() / 4);
             for (int k = 0; k < 4; ++k) ctx->sc_bvh_lds.bvh_off[k] = off[k];
             ctx->sc_bvh_lds.bvh = BvhView{nullptr, nullptr, nullptr, matInLds ? nullptr : ctx->mat_dev, bv.root_ref, bv.n_spheres, {0, 0, 0}, {1, 1, 1}};

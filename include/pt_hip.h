@@ -7,15 +7,22 @@
  * with its samplers (src/utils.h:71-138).  The reference has no plugin or FFI interface; the
  * one seam is the thread-pool work item `run_thread_batch(.., ThreadData*, ..)` whose inputs are a read-only
  * World + Camera + BVH and whose output is Image.pixels.  The functions below take exactly those inputs
- * (flattened to plain arrays) and produce exactly that output; INTEGRATION.md shows the 30-line change to
- * the reference's main() that binds them.
+ * (flattened to plain arrays) and produce that output; INTEGRATION.md shows the 30-line change to the
+ * reference's main() that binds them.  Two stated deviations: the RNG is Philox, not the
+ * reference's thread-local MT19937, so agreement is bit-exact per function on identical uniforms and statistical per
+ * image; and the sphere query returns the true closest hit, not the result of the reference BVH's pairwise combine
+ * (src/main.cpp:78-87), which drops 0.1-0.2 % of secondary hits -- converged images sit at 44.0 dB PSNR against the
+ * reference renderer where two reference runs agree to 50.6 dB (mean relative error 0.36 % vs 0.31 %).
  *
  * Conventions: every entry point returns an int status (0 = PT_OK, negative = pt_status); nothing aborts or
  * throws across the boundary (the reference is built /EHa- /GR-, src/build.bat:7).  The caller owns all host
  * buffers before and after each call; the library copies on upload and owns its device memory inside pt_ctx.
- * A pt_ctx is bound to one GPU and is driven by one host thread at a time; distinct contexts are independent.
- * The result depends only on (scene, params): never on the GPU count, launch geometry or scheduling, because
- * the RNG is Philox4x32-10 keyed by (seed, pixel, global sample index)  (DESIGN.md "RNG").
+ * A pt_ctx is bound to one GPU and is driven by one host thread at a time, with ONE render in flight at a time: the
+ * unit cursor, statistics, partial images and timing events are per context, so a render enqueued on another stream
+ * waits (on the device) for the context's previous one; distinct contexts are independent.
+ * The SAMPLES of a frame depend only on (scene, params) -- never on the GPU count, launch geometry or scheduling --
+ * because the RNG is Philox4x32-10 keyed by (seed, pixel, global sample index) (DESIGN.md "RNG").  The ORDER in which
+ * a pixel's samples are added is the run's by default (sums equal to a few ulp); PT_FLAG_REPRODUCIBLE fixes it too.
  */
 #ifndef PT_HIP_H
 #define PT_HIP_H
@@ -79,10 +86,13 @@ typedef struct pt_params {
  *   PT_FLAG_FORCE_LDS  : fail with PT_ERR_UNSUPPORTED rather than read the scene from HBM
  * How the per-pixel sums are formed (the samples are the same either way, each exactly once):
  *   default            : a wave starts its next (tile, sample-chunk) unit while the last paths of the previous one are
- *                        still under way; the order of the float additions into a pixel then depends on the run, and
- *                        two renders of one frame can differ in the last bits of a sum (a few ulp)
- *   PT_FLAG_REPRODUCIBLE: every unit is finished before the next one starts: the same launch gives the same bits,
- *                        run to run (~6 % slower on the bench workload) */
+ *                        still under way, and the units of a pixel's sample chunks ADD their sums to the output with
+ *                        float atomics; the order of the additions into a pixel then depends on the run, and two
+ *                        renders of one frame can differ in the last bits of a sum (a few ulp).  No scratch images.
+ *   PT_FLAG_REPRODUCIBLE: every unit is finished before the next one starts and each sample chunk goes to a partial image
+ *                        of its own (context-owned scratch, width*height*16 bytes per chunk, allocated on first use and
+ *                        kept), folded in chunk order: the same launch gives the same bits, run to run (~6 % slower on
+ *                        the bench workload) */
 #define PT_FLAG_STRICT_SEARCH 1u
 #define PT_FLAG_FORCE_BVH 2u
 #define PT_FLAG_FORCE_LDS 4u
@@ -98,7 +108,7 @@ typedef struct pt_stats {
     uint64_t phase_cycles[3]; /* diagnostic builds (-DPT_STAMPS) only: shader cycles in refill / closest-hit / shading; else 0 */
     double kernel_ms;       /* HIP-event time of the render kernel on its stream */
     uint32_t kernel;        /* 0 = LDS brute force (fast), 1 = BVH in HBM, 2 = LDS brute force (strict), 3 = BVH in LDS */
-    uint32_t reserved;
+    uint32_t node_bytes;    /* bytes per tree node the BVH kernels read: 64 (float boxes) or 32 (16-bit grid boxes); 0 without a tree */
 } pt_stats;
 
 /* ---- device / context -------------------------------------------------------------------------------- */
@@ -119,7 +129,8 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* scene);
 int pt_hip_render(pt_ctx* ctx, const pt_params* params, float* accum_rgba_host);
 
 /* Same, into caller-owned DEVICE memory on a caller-owned stream (hipStream_t as void*; NULL = default stream).
- * Asynchronous: returns after enqueueing.  This is what a multi-GPU driver all-reduces (RCCL) before resolving.
+ * Asynchronous: returns after enqueueing (a PT_FLAG_REPRODUCIBLE frame bigger than any before it on this context first
+ * grows the context's scratch with hipMalloc; the default mode never allocates).  image width*height < 2^31.  This is what a multi-GPU driver all-reduces (RCCL) before resolving.
  * accum_rgba_dev: 16-byte aligned, ordinary device memory of this GPU (hipMalloc / a torch CUDA tensor): without
  * PT_FLAG_REPRODUCIBLE the kernel may add to it with hardware FP32 atomics, which fine-grained or host-mapped
  * allocations do not guarantee. */

@@ -54,7 +54,7 @@ class Params(C.Structure):  # pt_params
 class Stats(C.Structure):  # pt_stats
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64), ("node_visits", C.c_uint64),
                 ("wave_iterations", C.c_uint64), ("phase_cycles", C.c_uint64 * 3),
-                ("kernel_ms", C.c_double), ("kernel", C.c_uint32), ("reserved", C.c_uint32)]
+                ("kernel_ms", C.c_double), ("kernel", C.c_uint32), ("node_bytes", C.c_uint32)]
 
 
 _lib = None
@@ -243,7 +243,7 @@ class Renderer:
 
     def _check(self, st, what):
         if st != PT_OK:
-            raise PtError(st, what, self.L.pt_hip_last_error(self.h).decode() if st == PT_ERR_HIP else "")
+            raise PtError(st, what, self.L.pt_hip_last_error(self.h).decode() if st in (PT_ERR_HIP, PT_ERR_UNSUPPORTED) else "")
 
     def upload(self, scene: Scene):
         self._check(self.L.pt_hip_upload_scene(self.h, C.byref(scene.desc)), "pt_hip_upload_scene")
@@ -271,7 +271,7 @@ class Renderer:
     def stats(self):
         s = Stats()
         self._check(self.L.pt_hip_last_stats(self.h, C.byref(s)), "pt_hip_last_stats")
-        d = {k: getattr(s, k) for k, _ in Stats._fields_ if k not in ("reserved", "phase_cycles")}
+        d = {k: getattr(s, k) for k, _ in Stats._fields_ if k != "phase_cycles"}
         d["phase_cycles"] = list(s.phase_cycles)
         return d
 

@@ -425,31 +425,25 @@ PT_DEV bool box_hit(float lox, float loy, float loz, float hix, float hiy, float
 constexpr float kConeEps = 1.0e-3f;
 PT_DEV bool cone_flat(float d) { return !(fabsf(d) > kConeEps * 1.001f); } // the cone outgrows this axis
 // lo planes go with (r2, n2), hi planes with (r1, n1); the coordinates are floats (64-byte nodes) or grid cells (32-byte
-// nodes, whose grid is folded into the pairs)
+// nodes, whose grid is folded into the pairs).  A flat axis needs no branch here: its hi-plane pair is (0, +big) (set up
+// once per ray in bvh_run), which makes that plane's value +big -- the axis then bounds t from below by its lo plane
+// alone and not from above: a superset of the cone/box overlap (the hi plane's lower bound is dropped), so conservative.
 PT_DEV bool cone_planes(float lox, float hix, float loy, float hiy, float loz, float hiz, float r1x, float r1y, float r1z, float n1x, float n1y, float n1z,
-                        float r2x, float r2y, float r2z, float n2x, float n2y, float n2z, bool anyFlat, V3 d, float best, float* tnear)
+                        float r2x, float r2y, float r2z, float n2x, float n2y, float n2z, float best, float* tnear)
 {
 #pragma clang fp contract(fast)
     const float a0 = lox * r2x + n2x, a1 = hix * r1x + n1x;
     const float b0 = loy * r2y + n2y, b1 = hiy * r1y + n1y;
     const float c0 = loz * r2z + n2z, c1 = hiz * r1z + n1z;
-    float nx = fminf(a0, a1), ny = fminf(b0, b1), nz = fminf(c0, c1);
-    float fx = fmaxf(a0, a1), fy = fmaxf(b0, b1), fz = fmaxf(c0, c1);
-    if (anyFlat) // ~1e-3 of rays per axis: both planes bound t from below, nothing bounds it from above
-    {
-        if (cone_flat(d.x)) { nx = fx; fx = kF32Max; }
-        if (cone_flat(d.y)) { ny = fy; fy = kF32Max; }
-        if (cone_flat(d.z)) { nz = fz; fz = kF32Max; }
-    }
-    const float tn = fmaxf(fmaxf(nx, ny), nz);
-    const float tf = fminf(fminf(fx, fy), fz);
+    const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+    const float tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
     *tnear = tn;
     return tf >= fmaxf(tn, 0.0f) && tn <= best;
 }
 PT_DEV bool box_hit_cone(float lox, float loy, float loz, float hix, float hiy, float hiz, float r1x, float r1y, float r1z, float n1x, float n1y, float n1z,
-                         float r2x, float r2y, float r2z, float n2x, float n2y, float n2z, bool anyFlat, V3 d, float best, float* tnear)
+                         float r2x, float r2y, float r2z, float n2x, float n2y, float n2z, float best, float* tnear)
 {
-    return cone_planes(lox, hix, loy, hiy, loz, hiz, r1x, r1y, r1z, n1x, n1y, n1z, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, d, best, tnear);
+    return cone_planes(lox, hix, loy, hiy, loz, hiz, r1x, r1y, r1z, n1x, n1y, n1z, r2x, r2y, r2z, n2x, n2y, n2z, best, tnear);
 }
 
 struct QueryCtx // per-lane scratch and counters of the sphere query
@@ -523,16 +517,18 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
     {
         auto cone_axis = [](float o, float d, float& r1, float& n1, float& r2, float& n2)
         {
-            // (on a flat axis d - eps and d + eps straddle zero; keep both away from it so the reciprocals stay finite)
+            // hi plane: t (d - eps) <= hi - o; lo plane: t (d + eps) >= lo - o.  On a flat axis (|d| <= eps) d - eps and
+            // d + eps straddle zero: both planes bound t from below, nothing bounds it from above.  There the hi-plane
+            // pair becomes (0, +big) -- its value is +big for every box, i.e. "no upper bound", and its lower bound is
+            // given up (conservative) -- and the lo-plane divisor is kept away from zero so the reciprocal stays finite.
             const bool flat = cone_flat(d);
-            const float s1 = flat ? fminf(d - kConeEps, -kConeEps * 1.0e-3f) : d - kConeEps;
             const float s2 = flat ? fmaxf(d + kConeEps, kConeEps * 1.0e-3f) : d + kConeEps;
-            r1 = __builtin_amdgcn_rcpf(s1); n1 = -o * r1;
             r2 = __builtin_amdgcn_rcpf(s2); n2 = -o * r2;
+            r1 = __builtin_amdgcn_rcpf(d - kConeEps); n1 = -o * r1;
+            if (flat) { r1 = 0.0f; n1 = 1.0e30f; }
         };
         cone_axis(ray.o.x, ray.d.x, ix, nox, r2x, n2x); cone_axis(ray.o.y, ray.d.y, iy, noy, r2y, n2y); cone_axis(ray.o.z, ray.d.z, iz, noz, r2z, n2z);
     }
-    const bool anyFlat = CONE && (cone_flat(ray.d.x) || cone_flat(ray.d.y) || cone_flat(ray.d.z));
     if constexpr (QN) // fold the node grid into the per-plane pairs: (r, n) -> (step * r, org * r + n)
     {
         nox = b.gorg[0] * ix + nox; noy = b.gorg[1] * iy + noy; noz = b.gorg[2] * iz + noz;
@@ -571,9 +567,9 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
                     const uint32_t lx = __float_as_uint(qa.x), ly = __float_as_uint(qa.y), lz = __float_as_uint(qa.z);
                     const uint32_t rx = __float_as_uint(qa.w), ry = __float_as_uint(qb.x), rz = __float_as_uint(qb.y);
                     hitL = cone_planes((float)(lx & 0xFFFFu), (float)(lx >> 16), (float)(ly & 0xFFFFu), (float)(ly >> 16), (float)(lz & 0xFFFFu), (float)(lz >> 16),
-                                       ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearL);
+                                       ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, cull, &nearL);
                     hitR = cone_planes((float)(rx & 0xFFFFu), (float)(rx >> 16), (float)(ry & 0xFFFFu), (float)(ry >> 16), (float)(rz & 0xFFFFu), (float)(rz >> 16),
-                                       ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearR);
+                                       ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, cull, &nearR);
                     refL = __float_as_uint(qb.z); refR = __float_as_uint(qb.w);
                 }
                 else
@@ -582,9 +578,9 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
                     // the two references are half of the node's last 16 bytes: an 8-byte load (from HBM the compiler would fetch all 16)
                     const float2 n3 = *reinterpret_cast<const float2*>(b.nodes + 4 * cur + 3);
                     // left box {n0.xyz .. n0.w, n1.x, n1.y}, right box {n1.z, n1.w, n2.x .. n2.yzw}
-                    hitL = CONE ? box_hit_cone(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearL)
+                    hitL = CONE ? box_hit_cone(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, cull, &nearL)
                                 : box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, cull, &nearL);
-                    hitR = CONE ? box_hit_cone(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearR)
+                    hitR = CONE ? box_hit_cone(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, cull, &nearR)
                                 : box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, cull, &nearR);
                     refL = __float_as_uint(n3.x); refR = __float_as_uint(n3.y);
                 }
@@ -670,7 +666,15 @@ struct Hit { float t; int32_t prim; V3 point, normal; Material m; };
 // How the sphere query is answered.
 enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2, MODE_BVH_LDS = 3, MODE_BVH_Q = 4 };
 constexpr bool mode_is_bvh(int m) { return m == MODE_BVH || m == MODE_BVH_LDS || m == MODE_BVH_Q; }
-constexpr bool mode_in_hbm(int m) { return m == MODE_BVH || m == MODE_BVH_Q; } // tree read from HBM: cone test // BVH: tree in HBM; BVH_LDS: tree staged in LDS
+constexpr bool mode_in_hbm(int m) { return m == MODE_BVH || m == MODE_BVH_Q; } // BVH / BVH_Q: tree read from HBM; BVH_LDS: tree staged in LDS
+// Which traversals test boxes against a cone around the ray (box_hit_cone): all of them.  The cone is what makes the
+// tree agree with the brute-force definition of the query wherever the reference's sphere formula reports phantom hits
+// (far from the ray origin: big scenes, and rays that come back from a distant point of an infinite plane).
+#ifdef PT_LDS_PLAIN_BOXES // experiments only: the tree-in-LDS kernel with plain boxes (round 1's state)
+constexpr bool mode_uses_cone(int m) { return mode_in_hbm(m); }
+#else
+constexpr bool mode_uses_cone(int m) { return mode_is_bvh(m); }
+#endif
 
 // First half of cast_ray (main.cpp:180-216): planes linearly, then the sphere query; closest wins, planes win ties.
 // plane loop (main.cpp:186-200): closest plane hit, or kF32Max / -1
@@ -732,7 +736,7 @@ template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, cons
     {
         TravState ts;
         trav_begin(q.bvh, planeT, planeIdx, live, q, ts);
-        bvh_run<MOVING, mode_in_hbm(MODE), MODE == MODE_BVH_Q>(q.bvh, ray, time, live, q, ts, 0u);
+        bvh_run<MOVING, mode_uses_cone(MODE), MODE == MODE_BVH_Q>(q.bvh, ray, time, live, q, ts, 0u);
         return make_hit_bvh<MOVING>(s, ray, time, q, ts);
     }
     int32_t obj;

@@ -86,7 +86,9 @@ struct RenderArgs
     uint32_t nchunks, nunits;       // work units = ntiles x nchunks; chunk c covers the samples chunk_range() gives it
     uint32_t chunk_ratio_q16, chunk_min; // the guided schedule's two parameters (chunk_size)
     float* out_sum;                 // width*height*4
-    float* partial;                 // nchunks > 1: [nchunks][height][width][4] per-chunk sums, folded in chunk order by k_fold_chunks
+    float* partial;                 // PT_FLAG_REPRODUCIBLE and nchunks > 1: [nchunks][height][width][4] per-chunk sums, folded in chunk order by k_fold_chunks
+    uint32_t chunk_stride;          // pixels between the images of two chunks: width*height with `partial`, else 0
+    uint32_t accumulate;            // nchunks > 1 without `partial`: every unit ADDS its tile to out_sum (zeroed before the launch)
     unsigned long long* stats;      // [0] segments ... [8] low word: the unit cursor the waves pull from
 };
 
@@ -96,7 +98,7 @@ struct RenderArgs
 // `minSpp`; a remainder below 2 x minSpp goes in one piece).  Host and device run the same recurrence.
 __host__ __device__ inline uint32_t chunk_size(uint32_t remaining, uint32_t ratio_q16, uint32_t minSpp)
 {
-    if (remaining < 2u * minSpp) return remaining;
+    if (minSpp == 0u || remaining < 2u * minSpp) return remaining; // (minSpp 0 cannot advance: one piece)
     uint32_t u = (uint32_t)(((unsigned long long)remaining * ratio_q16) >> 16);
     if (u > remaining / 2u) u = remaining / 2u;
     if (u < minSpp) u = minSpp;
@@ -106,6 +108,12 @@ __host__ __device__ inline uint32_t chunk_size(uint32_t remaining, uint32_t rati
 constexpr uint32_t kStatWords = 16;        // stats buffer: totals [0..7] counters, [8] unit cursor, [9..12] stamps; then one such record per wave
 constexpr uint32_t kWavesPerBlock = 4;     // LDS modes: four waves share one staged copy of the scene
 constexpr uint32_t kWavesPerBlockBvh = 1;  // tree in HBM: nothing to share, one wave per workgroup packs best
+
+// Limits of a launch on fixed-size scratch (render_launch's `fixed`): wave slots of the statistics buffer and bytes of
+// per-chunk partial images.
+constexpr uint32_t kStaticSlots = 8192;
+constexpr size_t kStaticStatsBytes = (((size_t)kStatWords * (1u + kStaticSlots) * sizeof(unsigned long long)) + 255u) / 256u * 256u;
+constexpr size_t kStaticPartialBytes = 32u << 20;
 
 // ================================================================================================ the hot kernel
 template <bool MOVING, int MODE, bool RESUME, bool CARRY>
@@ -146,7 +154,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     float time = 0.0f;
     uint32_t depth = 0, p = 0;
     constexpr uint32_t kCarried = 0x80000000u;
-    float* const image = a.nchunks > 1u ? a.partial : a.out_sum;
+    float* const image = a.partial ? a.partial : a.out_sum;
     // BVH kernels: a lane's sphere query may span several trips (bvh_run's early exit); ts.cur != kBvhDone marks a
     // lane whose query is under way.
     constexpr bool kBvh = RESUME && mode_is_bvh(MODE);
@@ -210,7 +218,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
             {
                 // The pool is empty: whoever is still under way is carried (its tile pixel becomes an index into the image).
                 if (alive && !(p & kCarried))
-                    p = kCarried | (chunk * (a.width * a.height) + (ty * 8u + (p >> 3)) * a.width + tx * 8u + (p & 7u));
+                    p = kCarried | (chunk * a.chunk_stride + (ty * 8u + (p >> 3)) * a.width + tx * 8u + (p & 7u));
                 break;
             }
             if (pt_ballot(alive) == 0ull)
@@ -232,7 +240,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
                     const float planeT = closest_plane(s, ray, &planeIdx);
                     trav_begin(qc.bvh, planeT, planeIdx, alive, qc, ts);
                 }
-                bvh_run<MOVING, mode_in_hbm(MODE), MODE == MODE_BVH_Q>(qc.bvh, ray, time, alive, qc, ts, a.sc.exit_lanes);
+                bvh_run<MOVING, mode_uses_cone(MODE), MODE == MODE_BVH_Q>(qc.bvh, ray, time, alive, qc, ts, a.sc.exit_lanes);
                 ready = alive && ts.cur == kBvhDone;
                 if (ready) h = make_hit_bvh<MOVING>(s, ray, time, qc, ts);
             }
@@ -270,17 +278,35 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
 #endif
         }
 
-        // ---- one 16-byte store per pixel and unit (plus the carried paths' atomics: the only HBM traffic of the render
-        // besides staging the scene).  The store must have landed before a carried path of this unit adds to it.
+        // ---- the unit's tile goes to the image (plus the carried paths' atomics: the only HBM traffic of the render
+        // besides staging the scene).
         if (haveUnit)
         {
-            const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
-            if (px < a.width && py < a.height)
+            if (a.accumulate)
             {
-                float4 v = make_float4(acc[lane * 4u], acc[lane * 4u + 1u], acc[lane * 4u + 2u], acc[lane * 4u + 3u]);
-                reinterpret_cast<float4*>(image)[(size_t)chunk * a.width * a.height + (size_t)py * a.width + px] = v;
+                // Several chunks, one image: the tile is ADDED to it (the host zeroed it).  One instruction covers two
+                // tile rows of 8 pixels x rgba = 2 x 128 contiguous bytes (the shape float atomics run at full rate in,
+                // MI355X_MICROARCH.md "Global float atomics"); lane l of instruction j holds acc[64 j + l].  Atomic
+                // adds commute: no ordering against the carried paths' adds, nothing to wait for.
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j)
+                {
+                    const uint32_t py = ty * 8u + 2u * j + (lane >> 5), px = tx * 8u + ((lane & 31u) >> 2);
+                    if (px < a.width && py < a.height)
+                        unsafeAtomicAdd(image + 4u * ((size_t)py * a.width + tx * 8u) + (lane & 31u), acc[j * 64u + lane]);
+                }
             }
-            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+            else
+            {
+                // one 16-byte store per pixel and unit; it must have landed before a carried path of this unit adds to it
+                const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
+                if (px < a.width && py < a.height)
+                {
+                    float4 v = make_float4(acc[lane * 4u], acc[lane * 4u + 1u], acc[lane * 4u + 2u], acc[lane * 4u + 3u]);
+                    reinterpret_cast<float4*>(image)[(size_t)chunk * a.chunk_stride + (size_t)py * a.width + px] = v;
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+            }
             if (lane == 0) unit = cursorBase + atomicAdd(reinterpret_cast<unsigned int*>(a.stats + 8), 1u);
             unit = pt_uniform(unit);
         }
@@ -527,6 +553,8 @@ struct pt_ctx
     float* partial_dev = nullptr; size_t partial_floats = 0; // per-chunk sums of a chunked launch (grown on demand, kept)
     int num_cus = 0;
     unsigned long long* stats_dev = nullptr;
+    unsigned long long* last_stats_dev = nullptr; // where the last launch left its counters (stats_dev or the static scratch)
+    unsigned char* static_scratch = nullptr;      // this device's copy of g_static_scratch (pt_hip_render_device_static)
     uint32_t stat_slots = 0;
     bool bvh_q = false;   // the tree in HBM is stored as 32-byte grid nodes (MODE_BVH_Q)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -534,6 +562,8 @@ struct pt_ctx
     int last_mode = MODE_LDS_FAST;
     pt_stats last{};
     size_t lds_limit = 0;
+    struct Occ { const void* kern; int block; size_t lds; int wgs; };
+    std::vector<Occ> occ;   // answers of the occupancy query (render_occupancy)
 };
 
 namespace {
@@ -627,15 +657,19 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
 constexpr uint64_t kGuide = 48;        // guided schedule: a unit is at most 1/kGuide of a resident wave's even share of what is left (tile cost varies ~10x: measured optimum 32-64)
 constexpr uint32_t kMinChunkSpp = 8;   // never cut a tile's samples finer than this (every unit has fixed costs; measured: 4 and 16 are no better)
 constexpr uint32_t kMaxChunks = 4096;  // (the walk in the kernel is linear in the chunk index)
-constexpr uint64_t kMaxPartialBytes = 4ull << 30; // per-chunk partial images the context may hold
+constexpr uint64_t kMaxPartialBytes = 4ull << 30; // per-chunk partial images the context may hold (PT_FLAG_REPRODUCIBLE frames only)
 
 // Workgroups of the render kernel for (moving, mode) one CU holds at this block size and LDS footprint.
+// (Asked once per kernel, shape and footprint, then remembered: a frame loop repeats the same few questions.)
 int render_occupancy(pt_ctx* ctx, bool moving, int mode, bool resume, bool carry, int block, size_t lds, int* out)
 {
     const RenderKernel kern = render_kernel(moving, mode, resume, carry);
+    for (const pt_ctx::Occ& o : ctx->occ)
+        if (o.kern == reinterpret_cast<const void*>(kern) && o.block == block && o.lds == lds) { *out = o.wgs; return PT_OK; }
     int st = set_lds(ctx, kern, lds);
     if (st != PT_OK) return st;
     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(out, kern, block, lds));
+    ctx->occ.push_back(pt_ctx::Occ{reinterpret_cast<const void*>(kern), block, lds, *out});
     return PT_OK;
 }
 
@@ -844,14 +878,20 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
     return PT_OK;
 }
 
-int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void* stream_)
+// One frame: the body of pt_hip_render_device and of pt_hip_render_device_static.  `fixed` = the scratch is the
+// per-device static array (nothing is allocated, bigger needs are refused); else the context's own, grown on demand.
+static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipStream_t stream, bool fixed)
 {
     int st = check_scene(ctx);
     if (st != PT_OK) return st;
+    ctx->err.clear();
     if (!p || !accum_dev || p->width == 0 || p->height == 0 || p->spp_end <= p->spp_begin) return PT_ERR_INVALID;
-    if ((uint64_t)p->width * p->height > 0xFFFFFFFFull || (uint64_t)(p->spp_end - p->spp_begin) * 64ull > 0xFFFFFFFFull) return PT_ERR_INVALID;
+    // (a carried path keeps its pixel's index in 31 bits; an item index = 64 x samples of a chunk in 32)
+    if ((uint64_t)p->width * p->height >= 0x80000000ull || (uint64_t)(p->spp_end - p->spp_begin) * 64ull > 0xFFFFFFFFull) return PT_ERR_INVALID;
     Bind b(ctx);
-    hipStream_t stream = (hipStream_t)stream_;
+    unsigned long long* const stats_dev = fixed ? reinterpret_cast<unsigned long long*>(ctx->static_scratch) : ctx->stats_dev;
+    const uint32_t stat_slots = fixed ? kStaticSlots : ctx->stat_slots;
+    if (fixed && !ctx->static_scratch) { ctx->err = "the static scratch array has no address on this device"; return PT_ERR_HIP; }
     int mode; const SceneArgs* sc; size_t lds = 0;
     // Workgroup shape: the waves of a workgroup share one staged copy of the scene, so bigger workgroups spend less LDS
     // per wave; take the shape that keeps the most waves resident on a CU (ties: the smaller workgroup).  With the tree
@@ -885,7 +925,7 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     a.ntiles = a.tiles_x * ((p->height + 7) / 8);
     a.tile_stride = pick_stride(a.ntiles);
     a.spp_begin = p->spp_begin; a.nspp = p->spp_end - p->spp_begin; a.max_depth = p->max_depth; a.seed = p->seed;
-    a.out_sum = accum_dev; a.stats = ctx->stats_dev;
+    a.out_sum = accum_dev; a.stats = stats_dev;
     // Persistent launch: as many workgroups as the chip holds at once; waves pull (tile, sample chunk) units.
     const dim3 block(64 * waves);
     const uint64_t slots = (uint64_t)wgPerCu * (uint64_t)ctx->num_cus * waves; // waves resident at once
@@ -898,37 +938,67 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
     uint64_t ratio = ((uint64_t)a.ntiles << 16) / (guide * slots);
     if (ratio > 0x8000u) ratio = 0x8000u;
     if (getenv("PT_UNIFORM_CHUNKS")) ratio = 0;                                                          // tuning experiments only
+    // Several chunks per tile meet in one image.  Default: every unit adds its tile to the output (float atomics; the
+    // order of the additions into a pixel is the run's, like the carried paths').  PT_FLAG_REPRODUCIBLE: one partial
+    // image per chunk in scratch, folded in chunk order by k_fold_chunks.
+    const bool reproducible = (p->flags & PT_FLAG_REPRODUCIBLE) != 0;
+    const uint64_t frameBytes = (uint64_t)p->width * p->height * 16ull;
     uint32_t nchunks = 0;
     for (;;)
     {
         nchunks = 0;
         for (uint32_t s0 = 0; s0 < a.nspp; ++nchunks) s0 += chunk_size(a.nspp - s0, (uint32_t)ratio, minSpp);
-        if (nchunks <= kMaxChunks && (uint64_t)nchunks * p->width * p->height * 16ull <= kMaxPartialBytes) break;
+        if (nchunks == 1) break;                     // one piece: no partial images, nothing to bound
+        if (nchunks <= kMaxChunks && (!reproducible || fixed || (uint64_t)nchunks * frameBytes <= kMaxPartialBytes)) break;
+        if (minSpp > 0x40000000u) { ratio = 0; minSpp = a.nspp; continue; } // (cannot get coarser: one chunk)
         minSpp *= 2; // (tiny images with huge sample counts) coarser chunks: fewer partial images
     }
     a.chunk_ratio_q16 = (uint32_t)ratio; a.chunk_min = minSpp;
     a.nchunks = nchunks;
     if ((uint64_t)a.ntiles * nchunks > 0xFFFFFF00ull) return PT_ERR_INVALID;
     a.nunits = a.ntiles * nchunks;
-    if (nchunks > 1)
+    a.partial = nullptr; a.chunk_stride = 0; a.accumulate = 0;
+    if (nchunks > 1 && reproducible)
     {
-        const size_t floats = (size_t)p->width * p->height * 4 * nchunks;
-        if (floats > ctx->partial_floats)
+        const uint64_t bytes = (uint64_t)nchunks * frameBytes;
+        if (fixed)
         {
-            if (ctx->partial_dev) { (void)hipFree(ctx->partial_dev); ctx->partial_dev = nullptr; ctx->partial_floats = 0; }
-            HIPCHK(ctx, hipMalloc((void**)&ctx->partial_dev, floats * sizeof(float)));
-            ctx->partial_floats = floats;
+            // same schedule as pt_hip_render_device (the frame must come out bit-identical), so the need is what it is
+            if (bytes > kStaticPartialBytes)
+            {
+                ctx->err = "pt_hip_render_device_static: a PT_FLAG_REPRODUCIBLE frame of " + std::to_string(p->width) + "x" + std::to_string(p->height) + " in " +
+                           std::to_string(nchunks) + " sample chunks needs " + std::to_string(bytes) + " bytes of scratch, the static maximum is " + std::to_string(kStaticPartialBytes);
+                return PT_ERR_UNSUPPORTED;
+            }
+            a.partial = reinterpret_cast<float*>(ctx->static_scratch + kStaticStatsBytes);
         }
-        a.partial = ctx->partial_dev;
+        else
+        {
+            const size_t floats = (size_t)(bytes / 4);
+            if (floats > ctx->partial_floats)
+            {
+                if (ctx->partial_dev) { (void)hipFree(ctx->partial_dev); ctx->partial_dev = nullptr; ctx->partial_floats = 0; }
+                HIPCHK(ctx, hipMalloc((void**)&ctx->partial_dev, floats * sizeof(float)));
+                ctx->partial_floats = floats;
+            }
+            a.partial = ctx->partial_dev;
+        }
+        a.chunk_stride = p->width * p->height;
     }
+    else if (nchunks > 1)
+        a.accumulate = 1;
     uint64_t wgs = ((uint64_t)a.nunits + waves - 1) / waves;
     if (wgs > (uint64_t)wgPerCu * ctx->num_cus) wgs = (uint64_t)wgPerCu * ctx->num_cus;
     const dim3 grid((uint32_t)wgs);
     if (getenv("PT_VERBOSE"))
         fprintf(stderr, "pt_hip: render mode %d, %u waves/WG, LDS %zu B/WG, %d WG/CU, grid %u, %u tiles x %u chunks\n", mode, waves, lds, wgPerCu, grid.x, a.ntiles, nchunks);
     const uint32_t nslots = grid.x * waves;
-    if (nslots > ctx->stat_slots) { ctx->err = "launch larger than the statistics buffer"; return PT_ERR_UNSUPPORTED; }
-    HIPCHK(ctx, hipMemsetAsync(ctx->stats_dev, 0, (size_t)kStatWords * (1u + nslots) * sizeof(unsigned long long), stream));
+    if (nslots > stat_slots) { ctx->err = "launch larger than the statistics buffer"; return PT_ERR_UNSUPPORTED; }
+    // One launch of a context in flight at a time: the statistics words (the unit cursor among them), the partial images
+    // and the two events are per context.  A launch on another stream waits for the previous one here.
+    if (ctx->timed) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev1, 0));
+    HIPCHK(ctx, hipMemsetAsync(stats_dev, 0, (size_t)kStatWords * (1u + nslots) * sizeof(unsigned long long), stream));
+    if (a.accumulate) HIPCHK(ctx, hipMemsetAsync(accum_dev, 0, (size_t)frameBytes, stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     {
         const RenderKernel kern = render_kernel(ctx->moving, mode, a.sc.exit_lanes != 0, !(p->flags & PT_FLAG_REPRODUCIBLE));
@@ -937,23 +1007,30 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
     }
     HIPCHK(ctx, hipGetLastError());
-    if (nchunks > 1)
+    if (a.partial)
     {
         const uint32_t n = p->width * p->height;
         uint32_t blocks = (n + 255) / 256;
         if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(k_fold_chunks, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(ctx->partial_dev), nchunks, n, reinterpret_cast<float4*>(accum_dev));
+        hipLaunchKernelGGL(k_fold_chunks, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(a.partial), nchunks, n, reinterpret_cast<float4*>(accum_dev));
     }
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_sum_stats, dim3((nslots + 255u) / 256u), dim3(256), 0, stream, ctx->stats_dev, nslots);
+    hipLaunchKernelGGL(k_sum_stats, dim3((nslots + 255u) / 256u), dim3(256), 0, stream, stats_dev, nslots);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
+    ctx->last_stats_dev = stats_dev;
     ctx->last_mode = mode;
     ctx->last = pt_stats{};
     ctx->last.samples = (uint64_t)p->width * p->height * a.nspp;
     ctx->last.kernel = mode_in_hbm(mode) ? 1u : mode == MODE_BVH_LDS ? 3u : mode == MODE_LDS_STRICT ? 2u : 0u;
+    ctx->last.node_bytes = mode == MODE_BVH_Q ? 32u : mode_is_bvh(mode) ? 64u : 0u;
     return PT_OK;
+}
+
+int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void* stream_)
+{
+    return render_launch(ctx, p, accum_dev, (hipStream_t)stream_, false);
 }
 
 int pt_hip_render(pt_ctx* ctx, const pt_params* p, float* accum_host)
@@ -984,7 +1061,7 @@ int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out)
     float ms = 0.0f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     unsigned long long st[8];
-    HIPCHK(ctx, hipMemcpy(st, ctx->stats_dev, sizeof(st), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(st, ctx->last_stats_dev, sizeof(st), hipMemcpyDeviceToHost));
     ctx->last.kernel_ms = ms;
     ctx->last.segments = st[0];
     ctx->last.wave_iterations = st[1];
@@ -1086,7 +1163,7 @@ int pt_hip_debug_counters(pt_ctx* ctx, uint64_t out16[16])
     if (!ctx->timed) return PT_ERR_NO_SCENE;
     Bind b(ctx);
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
-    HIPCHK(ctx, hipMemcpy(out16, ctx->stats_dev, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out16, ctx->last_stats_dev, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

@@ -47,3 +47,18 @@ def mean_rel_error(img, ref, eps=1e-2):
     """Per-pixel mean relative error on linear RGB, the image gate of BASELINE.json (eps guards black pixels)."""
     img, ref = np.asarray(img, np.float64)[..., :3], np.asarray(ref, np.float64)[..., :3]
     return float(np.mean(np.abs(img - ref) / (np.abs(ref) + eps)))
+
+
+def in_threads(fn, arrays, nthreads=None):
+    """Run fn(*slices) over row-slices of `arrays` on several threads (the oracle's loops are single-threaded C and ctypes
+    releases the GIL); returns the outputs concatenated row-wise.  For the brute-force oracle over 10^6 spheres."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(arrays[0])
+    if nthreads is None:
+        nthreads = max(1, min(16, len(os.sched_getaffinity(0))))
+    cuts = np.linspace(0, n, nthreads + 1).astype(int)
+    spans = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    with ThreadPoolExecutor(len(spans)) as ex:
+        parts = list(ex.map(lambda ab: fn(*[x[ab[0]:ab[1]] for x in arrays]), spans))
+    return tuple(np.concatenate([p[k] for p in parts], 0) for k in range(len(parts[0])))

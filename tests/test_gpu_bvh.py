@@ -6,7 +6,7 @@ import pytest
 import pathtracer_amd as pt
 from oracle import pyoracle as po
 from tests import _gen
-from tests._util import bit_equal, to_pt_scene, builtin_scene_arrays
+from tests._util import bit_equal, to_pt_scene, builtin_scene_arrays, in_threads
 
 pytestmark = pytest.mark.gpu
 
@@ -180,5 +180,131 @@ def test_grid_nodes_bit_exact(renderer, oracle, monkeypatch, name):
         ref, seg = oracle.render_philox(h, 96, 54, 0, 12, 50, seed=19)
         assert st["kernel"] == 1 and st["segments"] == seg, name
         assert np.abs(img.astype(np.float64) - ref.astype(np.float64)).max() <= 2 * 12 * 2.0 ** -24 * max(1.0, float(np.abs(ref).max()))
+    finally:
+        oracle.scene_free(h)
+
+
+def test_c5_million_spheres_4k(renderer, oracle):
+    """BASELINE.json config 5 at its full size: 10^6 random spheres + ground plane, 3840x2160, depth 50, through the
+    default path (flags = 0: tree in HBM, 32-byte grid nodes).  A few spp of the whole frame for the size-independent
+    properties; bit-equality with the brute-force oracle (10^6 exact sphere tests per segment) on a strided subset of
+    rays and of whole samples."""
+    w, hgt, depth, spp = 3840, 2160, 50, 3
+    sa = builtin_scene_arrays(5, w / hgt, 1000000)
+    assert sa.n_spheres == 1000000
+    renderer.upload(to_pt_scene(sa))
+    img = renderer.render(w, hgt, 0, spp, depth, seed=12)
+    st = renderer.stats()
+    assert st["kernel"] == 1 and st["node_bytes"] == 32                              # tree in HBM, grid nodes
+    assert st["samples"] == w * hgt * spp
+    assert np.isfinite(img).all() and (img >= 0).all()
+    assert np.allclose(img[..., 3], spp, rtol=1e-6)                                  # every sample landed exactly once
+    assert (img[..., :3] <= spp * 1.0000001).all()
+    parts = renderer.render(w, hgt, 0, 1, depth, seed=12) + renderer.render(w, hgt, 1, spp, depth, seed=12)
+    assert np.abs(img - parts).max() <= 2 * spp * 2.0 ** -24 * spp                   # linear in the sample range
+    h = oracle.scene(sa)
+    try:
+        # (1) closest-hit records: camera rays + rays leaving sphere surfaces, all over the 1000-unit slab
+        rng = np.random.default_rng(31)
+        n = 3072
+        uv = rng.uniform(0, 1, size=(n, 2)).astype(np.float32)
+        cam_rays, _, _ = oracle.get_rays(sa.camera, 0, uv)
+        rays, times = _gen.scene_rays(rng, sa, n, cam_rays)
+        t, prim, p, nr = renderer.probe_hits(rays, times, 0)
+        to, po_, pto, nro = in_threads(lambda r, tm: oracle.closest_hits(h, r, tm, po.QUERY_CLOSEST), (rays, times))
+        assert (prim == po_).all(), int((prim != po_).sum())
+        assert bit_equal(t, to) and bit_equal(p, pto) and bit_equal(nr, nro)
+        assert (prim >= 0).sum() > n // 4                                            # the subset does hit spheres
+        # (2) whole samples of the frame above (same seed): a strided subset of pixels, first and last sample
+        ys, xs = np.meshgrid(np.arange(11, hgt, 241), np.arange(7, w, 307), indexing="ij")
+        pix = np.tile((ys * w + xs).reshape(-1).astype(np.uint32), 2)
+        smp = np.repeat(np.array([0, spp - 1], np.uint32), len(pix) // 2)
+        c, segs = renderer.probe_samples(w, hgt, pix, smp, depth, seed=12)
+        co, segso = in_threads(lambda px, sm: oracle.samples_philox(h, w, hgt, px, sm, depth, seed=12), (pix, smp))
+        assert (segs == segso).all() and bit_equal(c, co)
+        assert segs.mean() > 1.5
+    finally:
+        oracle.scene_free(h)
+
+
+def _far_flung_scene(n=200, extent=1000.0, seed=41):
+    """A handful of spheres spread over a thousand units: few enough for the tree-in-LDS kernel, far enough apart for the
+    reference's sphere formula (geometry.cpp:45-66) to report phantom hits."""
+    sa = _gen.random_scene(np.random.default_rng(seed), n, n_planes=1, extent=extent)
+    sa.pos_r[:, 3] = np.random.default_rng(seed + 1).uniform(0.3, 6.0, n).astype(np.float32)
+    sa.pos_r[:, 1] = sa.pos_r[:, 3] * np.random.default_rng(seed + 2).uniform(0.5, 3.0, n).astype(np.float32)
+    return sa
+
+
+def test_small_count_large_extent_through_the_default_kernel(renderer, oracle):
+    """~200 spheres over a 2000-unit field through flags = 0: the tree fits LDS (kernel 3), and the rays work a thousand
+    units from their origins, where the reference formula's cancellation (b*b - 4c from |o-c|^2 ~ 1e6) yields phantom
+    hits and orders real ones by noise.  The tree-in-LDS traversal tests boxes against the same cone as the tree in HBM,
+    so the answer is the brute-force oracle's, to the bit."""
+    sa = _far_flung_scene()
+    renderer.upload(to_pt_scene(sa))
+    h = oracle.scene(sa)
+    try:
+        rng = np.random.default_rng(43)
+        n = 60000
+        # rays between the spheres' neighbourhoods: from near one sphere towards (almost) another one, so that many of
+        # them graze their target inside the formula's error band at |o-c| of hundreds to a thousand units
+        a, b = rng.integers(0, sa.n_spheres, n), rng.integers(0, sa.n_spheres, n)
+        org = sa.pos_r[a, :3] + _gen.unit(rng.normal(size=(n, 3))) * (sa.pos_r[a, 3:4] * rng.uniform(1.001, 3.0, size=(n, 1)))
+        org[:, 1] = np.abs(org[:, 1]) + 1e-3
+        tgt = sa.pos_r[b, :3] + _gen.unit(rng.normal(size=(n, 3))) * (sa.pos_r[b, 3:4] * rng.uniform(0.0, 1.15, size=(n, 1)))
+        d = tgt - org
+        ok = np.linalg.norm(d, axis=1) > 1e-3
+        rays = np.concatenate([org[ok], _gen.unit(d[ok])], 1).astype(np.float32)
+        times = np.zeros(len(rays), np.float32)
+        t, prim, p, nr = renderer.probe_hits(rays, times, 0)
+        to, po_, pto, nro = oracle.closest_hits(h, rays, times, po.QUERY_CLOSEST)
+        assert (prim == po_).all(), int((prim != po_).sum())
+        assert bit_equal(t, to) and bit_equal(p, pto) and bit_equal(nr, nro)
+        # the case the cone exists for is present in the sample: hits the oracle reports although the ray misses the
+        # sphere geometrically (f64), i.e. phantom hits of the formula
+        hit = np.nonzero(po_ >= 0)[0]
+        c = sa.pos_r[po_[hit]].astype(np.float64)
+        oc = rays[hit, :3].astype(np.float64) - c[:, :3]
+        dd = rays[hit, 3:].astype(np.float64)
+        hb = np.einsum("ij,ij->i", oc, dd)
+        phantom = (hb * hb - (np.einsum("ij,ij->i", oc, oc) - c[:, 3] ** 2)) < 0
+        print(f"far-flung scene: {len(hit)} sphere hits of {len(rays)} rays, {int(phantom.sum())} of them phantom hits of the formula")
+        assert phantom.sum() >= 5
+        # whole frames and samples through the render kernel (k_render_w7, tree in LDS)
+        w, hgt, spp, depth = 96, 54, 6, 50
+        img = renderer.render(w, hgt, 0, spp, depth, seed=44)
+        st = renderer.stats()
+        ref, seg = oracle.render_philox(h, w, hgt, 0, spp, depth, seed=44)
+        assert st["kernel"] == 3 and st["segments"] == seg
+        assert np.abs(img.astype(np.float64) - ref.astype(np.float64)).max() <= 2 * spp * 2.0 ** -24 * max(1.0, float(np.abs(ref).max()))
+    finally:
+        oracle.scene_free(h)
+
+
+def test_rays_returning_from_far_out_on_the_ground_plane(renderer, oracle):
+    """Book-1 scene: the ground is an infinite plane, so diffuse bounces off it hundreds to ten thousand units out send
+    rays back into the sphere field with |o| far beyond the scene extent -- where the slab test's rounding (|o| 2^-24)
+    and the formula's phantom hits (8e-4 |o-c|) exceed any fixed box padding.  Default kernel (tree in LDS, cone test)
+    against the brute-force oracle, bit for bit."""
+    sa = builtin_scene_arrays(1, 16 / 9)
+    renderer.upload(to_pt_scene(sa))
+    h = oracle.scene(sa)
+    try:
+        rng = np.random.default_rng(51)
+        n = 60000
+        dist = 10.0 ** rng.uniform(2.0, 4.0, n)
+        ang = rng.uniform(0, 2 * np.pi, n)
+        org = np.stack([dist * np.cos(ang), np.full(n, 1e-3) * (1 + dist * 1e-3), dist * np.sin(ang)], 1)
+        k = rng.integers(0, sa.n_spheres, n)
+        tgt = sa.pos_r[k, :3] + _gen.unit(rng.normal(size=(n, 3))) * (sa.pos_r[k, 3:4] * rng.uniform(0.0, 1.5, size=(n, 1)))
+        rays = np.concatenate([org, _gen.unit(tgt - org)], 1).astype(np.float32)
+        times = np.zeros(n, np.float32)
+        to, po_, pto, nro = oracle.closest_hits(h, rays, times, po.QUERY_CLOSEST)
+        for flags in (0, pt.FLAG_FORCE_BVH):
+            t, prim, p, nr = renderer.probe_hits(rays, times, flags)
+            assert (prim == po_).all(), (flags, int((prim != po_).sum()))
+            assert bit_equal(t, to) and bit_equal(p, pto) and bit_equal(nr, nro), flags
+        assert (po_ >= 0).mean() > 0.3
     finally:
         oracle.scene_free(h)

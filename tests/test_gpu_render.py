@@ -161,7 +161,10 @@ def test_spp_slices_add_up(renderer):
     parts = renderer.render(w, h, 0, 5, depth, seed=1) + renderer.render(w, h, 5, 12, depth, seed=1)
     assert np.allclose(whole, parts, rtol=0, atol=12 * 8 * 2.0 ** -24)
     again = renderer.render(w, h, 0, 12, depth, seed=1)
-    assert bit_equal(whole, again)              # same launch geometry -> same bits
+    assert np.allclose(whole, again, rtol=0, atol=12 * 8 * 2.0 ** -24)   # default mode: same samples, order of the sums is the run's
+    a, b = (renderer.render(w, h, 0, 12, depth, seed=1, flags=pt.FLAG_REPRODUCIBLE) for _ in range(2))
+    assert bit_equal(a, b)                      # PT_FLAG_REPRODUCIBLE: same launch -> same bits
+    assert np.allclose(whole, a, rtol=0, atol=12 * 8 * 2.0 ** -24)
     other = renderer.render(w, h, 0, 12, depth, seed=2)
     assert not np.allclose(whole, other)        # the seed matters
 

@@ -136,6 +136,20 @@ int pt_hip_render(pt_ctx* ctx, const pt_params* params, float* accum_rgba_host);
  * allocations do not guarantee. */
 int pt_hip_render_device(pt_ctx* ctx, const pt_params* params, float* accum_rgba_dev, void* stream);
 
+/* The same frame as pt_hip_render_device, bit for bit, through an entry point that ALLOCATES NOTHING: no hipMalloc,
+ * hipFree or allocating library routine on any path.  No counterpart in the reference; it is for callers that cannot
+ * allocate: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  The scratch that
+ * pt_hip_render_device keeps in (and grows inside) the context -- the unit cursor and per-wave statistics records the
+ * persistent waves use, and the per-chunk partial images of a PT_FLAG_REPRODUCIBLE frame -- lives in a file-scope
+ * `static __device__` array instead (1 MiB of cursor/statistics for up to 8192 resident waves + 32 MiB of partial
+ * images per GPU, held until the process ends).  Limits: a PT_FLAG_REPRODUCIBLE frame whose sample chunks need more
+ * than 32 MiB of partial images (width*height*16 bytes per chunk) is refused with PT_ERR_UNSUPPORTED and a message in
+ * pt_hip_last_error; without that flag any frame size is served.  Every call on a GPU -- from any context -- shares
+ * that GPU's array: calls that overlap in time on one GPU race (serialise them on one stream, or use
+ * pt_hip_render_device for the concurrent ones); pt_hip_last_stats after it reads the shared array, so take the
+ * statistics before the next static call on that GPU.  accum_rgba_dev and params as for pt_hip_render_device. */
+int pt_hip_render_device_static(pt_ctx* ctx, const pt_params* params, float* accum_rgba_dev, void* stream);
+
 /* Statistics of the last render on this context (synchronises with it). */
 int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out);
 /* Host-only helper (no reference counterpart; touches no device): the sample-chunk schedule pt_hip_render_device uses

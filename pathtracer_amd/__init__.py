@@ -22,7 +22,7 @@ PRIM_MISS = -(2 ** 31)
 # Every symbol include/pt_hip.h declares (tests/test_abi.py checks the library exports exactly these).
 EXPORTS = (
     "pt_hip_device_count", "pt_hip_create", "pt_hip_destroy", "pt_hip_strerror", "pt_hip_last_error",
-    "pt_hip_upload_scene", "pt_hip_render", "pt_hip_render_device", "pt_hip_last_stats", "pt_hip_debug_counters", "pt_chunk_schedule", "pt_bvh_selfcheck", "pt_hip_resolve_device",
+    "pt_hip_upload_scene", "pt_hip_render", "pt_hip_render_device", "pt_hip_render_device_static", "pt_hip_last_stats", "pt_hip_debug_counters", "pt_chunk_schedule", "pt_bvh_selfcheck", "pt_hip_resolve_device",
     "pt_resolve", "pt_pack_bgra", "pt_bmp_write", "pt_bmp_write_bgra", "pt_bmp_header",
     "pt_scene_builtin", "pt_scene_get_desc", "pt_scene_free", "pt_scene_save", "pt_scene_load",
     "pt_hip_probe_primitives", "pt_hip_probe_hits", "pt_hip_probe_get_rays", "pt_hip_probe_scatter", "pt_hip_probe_paths",
@@ -92,6 +92,7 @@ def load_library(path=LIB_PATH):
     L.pt_hip_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
     L.pt_hip_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p]
     L.pt_hip_render_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]
+    L.pt_hip_render_device_static.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]
     L.pt_hip_last_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.pt_hip_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 16)]
     L.pt_chunk_schedule.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]
@@ -262,6 +263,10 @@ class Renderer:
 
     def render_device(self, params: Params, accum_dev_ptr: int, stream: int = 0):
         self._check(self.L.pt_hip_render_device(self.h, C.byref(params), C.c_void_p(accum_dev_ptr), C.c_void_p(stream)), "pt_hip_render_device")
+
+    def render_device_static(self, params: Params, accum_dev_ptr: int, stream: int = 0):
+        """pt_hip_render_device through the entry point that allocates nothing (scratch in a static device array)."""
+        self._check(self.L.pt_hip_render_device_static(self.h, C.byref(params), C.c_void_p(accum_dev_ptr), C.c_void_p(stream)), "pt_hip_render_device_static")
 
     def resolve_device(self, accum_dev_ptr, n_pixels, spp_total, pixels_dev_ptr=0, bgra_dev_ptr=0, stream=0):
         self._check(self.L.pt_hip_resolve_device(self.h, C.c_void_p(accum_dev_ptr), n_pixels, spp_total,

@@ -109,11 +109,14 @@ constexpr uint32_t kStatWords = 16;        // stats buffer: totals [0..7] counte
 constexpr uint32_t kWavesPerBlock = 4;     // LDS modes: four waves share one staged copy of the scene
 constexpr uint32_t kWavesPerBlockBvh = 1;  // tree in HBM: nothing to share, one wave per workgroup packs best
 
-// Limits of a launch on fixed-size scratch (render_launch's `fixed`): wave slots of the statistics buffer and bytes of
-// per-chunk partial images.
+// Scratch of pt_hip_render_device_static, the entry point that allocates nothing: the statistics words -- the unit cursor
+// the waves pull from and one record per wave (a 256-CU chip holds 8192 waves) -- and room for the per-chunk partial
+// images of a PT_FLAG_REPRODUCIBLE frame.  One copy per GPU, held until the process ends; in host code the name is a
+// stand-in, the array's address on a device comes from hipGetSymbolAddress (pt_hip_create) and is kept in the context.
 constexpr uint32_t kStaticSlots = 8192;
 constexpr size_t kStaticStatsBytes = (((size_t)kStatWords * (1u + kStaticSlots) * sizeof(unsigned long long)) + 255u) / 256u * 256u;
 constexpr size_t kStaticPartialBytes = 32u << 20;
+static __device__ __align__(256) unsigned char g_static_scratch[kStaticStatsBytes + kStaticPartialBytes];
 
 // ================================================================================================ the hot kernel
 template <bool MOVING, int MODE, bool RESUME, bool CARRY>
@@ -757,6 +760,8 @@ int pt_hip_create(int device, pt_ctx** out)
     c->lds_limit = kMaxLdsBytes;
     c->num_cus = prop.multiProcessorCount;
     c->stat_slots = (uint32_t)c->num_cus * 32u; // no launch holds more waves than the chip's 32 per CU
+    // (this device is current: the address is that of ITS copy of the array)
+    if (hipGetSymbolAddress((void**)&c->static_scratch, HIP_SYMBOL(g_static_scratch)) != hipSuccess) c->static_scratch = nullptr; // pt_hip_render_device_static then fails
     if (hipMalloc((void**)&c->stats_dev, (size_t)kStatWords * (1u + c->stat_slots) * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
     {
@@ -1031,6 +1036,11 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
 int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void* stream_)
 {
     return render_launch(ctx, p, accum_dev, (hipStream_t)stream_, false);
+}
+
+int pt_hip_render_device_static(pt_ctx* ctx, const pt_params* p, float* accum_dev, void* stream_)
+{
+    return render_launch(ctx, p, accum_dev, (hipStream_t)stream_, true);
 }
 
 int pt_hip_render(pt_ctx* ctx, const pt_params* p, float* accum_host)

@@ -31,8 +31,13 @@ $(LIBDIR)/pt_world.o: $(HOST)/pt_world.cpp $(HOST)/pt_world.h include/pt_hip.h
 	@mkdir -p $(LIBDIR)
 	g++ $(CXXFLAGS) -c $< -o $@
 
-$(LIBDIR)/libpt_hip.so: $(LIBDIR)/pt_hip.o $(LIBDIR)/pt_world.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@
+# pt_node.hip: host-only code (contexts, streams, RCCL bound with dlopen); hipcc for the HIP / RCCL headers
+$(LIBDIR)/pt_node.o: $(CSRC)/pt_node.hip include/pt_hip.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -fPIC -Wall -c $< -o $@
+
+$(LIBDIR)/libpt_hip.so: $(LIBDIR)/pt_hip.o $(LIBDIR)/pt_world.o $(LIBDIR)/pt_node.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -ldl -pthread
 
 oracle:
 	$(MAKE) -C oracle all
@@ -47,13 +52,13 @@ clean:
 .PHONY: all lib cli oracle isa clean
 
 # Diagnostic build with in-kernel s_memtime stamps (never shipped, never benchmarked: read its SHARES, not its speed).
-stamps: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h $(LIBDIR)/pt_world.o
+stamps: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h $(LIBDIR)/pt_world.o $(LIBDIR)/pt_node.o
 	$(HIPCC) $(HIPFLAGS) -DPT_STAMPS -c $(CSRC)/pt_hip.hip -o $(LIBDIR)/pt_hip_stamps.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(LIBDIR)/pt_hip_stamps.o $(LIBDIR)/pt_world.o -o $(LIBDIR)/libpt_hip_stamps.so
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(LIBDIR)/pt_hip_stamps.o $(LIBDIR)/pt_world.o $(LIBDIR)/pt_node.o -o $(LIBDIR)/libpt_hip_stamps.so -ldl -pthread
 
 # A/B experiment builds: make variant NAME=foo DEFS="-DPT_X -DPT_Y"  ->  pathtracer_amd/lib/ab/libpt_hip_foo.so (git-ignored)
-variant: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h $(LIBDIR)/pt_world.o
+variant: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h $(LIBDIR)/pt_world.o $(LIBDIR)/pt_node.o
 	mkdir -p $(LIBDIR)/ab
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c $(CSRC)/pt_hip.hip -o $(LIBDIR)/ab/pt_hip_$(NAME).o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(LIBDIR)/ab/pt_hip_$(NAME).o $(LIBDIR)/pt_world.o -o $(LIBDIR)/ab/libpt_hip_$(NAME).so
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(LIBDIR)/ab/pt_hip_$(NAME).o $(LIBDIR)/pt_world.o $(LIBDIR)/pt_node.o -o $(LIBDIR)/ab/libpt_hip_$(NAME).so -ldl -pthread
 	rm -f $(LIBDIR)/ab/pt_hip_$(NAME).o

@@ -59,6 +59,22 @@ def cpu_baseline(scene_id, w, h, depth, spp, threads):
             "sample": f"scene {scene_id} {w}x{h} depth {depth}, {spp} spp ({w * h * spp / 1e6:.1f} Msamples, {secs:.1f} s wall)"}
 
 
+def host_threads():
+    """Threads for the CPU baseline = the host cores this process may use: its affinity mask, further capped by the
+    cgroup CPU quota when one is set (a GPU box hands one GPU's job a share of the machine; threads beyond the quota
+    only get throttled).  Returns (threads, {"os_cpu_count", "affinity", "cgroup_quota"}) so the line states all three."""
+    n_aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    n = n_aff if quota is None else max(1, min(n_aff, int(quota + 0.5)))
+    return n, {"os_cpu_count": os.cpu_count(), "affinity": n_aff, "cgroup_quota": quota}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +87,7 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-brute", action="store_true", help="skip the extra launch of the brute-force kernel (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -156,18 +173,34 @@ def main():
         # an inner-node visit tests both child boxes (2 x 32 FLOP); leaf tests are per sphere
         f_sample = flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving, 2.0 * nvis / segs, stest / segs) if is_bvh else \
             flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving)
-        f_brute = flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving)
         # roofline of the dominant kernel (k_render), per launch on one GPU
         achieved = (w * h * S) * f_sample / (kernel_ms * 1e-3) / 1e12
-        traffic = None
+        # HBM bytes per launch come from PMC passes (rocprofv3 cannot run inside this process): tools/profile.sh runs
+        # THIS command under the counters and writes profiles/traffic.json in the same run that produces the kept
+        # summary; the line says which run that was.  No entry for this workload -> null.
+        traffic, traffic_run = None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                t = json.load(open(tf))
-                key = f"scene{args.scene}_{w}x{h}_spp{S}_d{depth}"
-                traffic = t.get(key, {}).get("hbm_bytes_per_launch")
+                t = json.load(open(tf)).get(f"scene{args.scene}_{w}x{h}_spp{S}_d{depth}", {})
+                traffic, traffic_run = t.get("hbm_bytes_per_launch"), t.get("run")
             except Exception:  # noqa: BLE001
                 traffic = None
+        # The formulation SURVEY.md 8(d) prices (brute force over the LDS-resident scene, packed FP32), MEASURED: one
+        # launch of that kernel on the same workload, outside the timed region.
+        brute = None
+        if world == 1 and is_bvh and not args.no_brute:
+            try:
+                pb = r.params(w, h, 0, S, depth, seed=args.seed, flags=pt.FLAG_BRUTE_FORCE)
+                r.render_device(pb, accum.data_ptr(), stream.cuda_stream)
+                sb = r.stats()
+                fb = flops_per_sample(sb["segments"] / sb["samples"], scene.n_spheres, scene.n_planes, moving)
+                tfl = sb["samples"] * fb / (sb["kernel_ms"] * 1e-3) / 1e12
+                brute = {"kernel": "k_render<brute force, scene in LDS> (PT_FLAG_BRUTE_FORCE), one launch outside the timed region",
+                         "kernel_ms": round(sb["kernel_ms"], 3), "Msamples/s": round(sb["samples"] / sb["kernel_ms"] / 1e3, 1),
+                         "flop_per_sample": round(fb, 1), "achieved": round(tfl, 2), "frac": round(tfl / PEAK_FP32_TFLOPS, 4)}
+            except pt.PtError:
+                brute = None   # the scene has no brute-force image in LDS
         out = {
             "metric": "Msamples/s (whole node) book-1 scene 1080p", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -177,20 +210,20 @@ def main():
                        "global_samples_per_step": samples_per_step, "parallelism": f"spp-split x{world} + RCCL all-reduce(sum) of the f32 accumulation buffer",
                        "segments_per_sample": round(sbar, 4), "lane_utilisation": round(st["segments"] / (64.0 * max(1, st["wave_iterations"])), 4), "kernel_ms": round(kernel_ms, 3), "lib_kernel_ms_last": round(st["kernel_ms"], 3)},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic, "traffic_run": traffic_run,
                          "kernel": kernel_name, "flop_per_sample": round(f_sample, 1),
                          "box_tests_per_segment": round(2.0 * nvis / segs, 2) if is_bvh else None,
                          "leaf_sphere_tests_per_segment": round(stest / segs, 2) if is_bvh else None,
-                         "brute_force_equivalent": {"flop_per_sample": round(f_brute, 1),
-                                                    "frac": round((w * h * S) * f_brute / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)},
+                         "brute_force_kernel": brute,
                          "note": "FP32 vector (VALU) roofline, not MFMA (BASELINE.json north_star). Algorithmic FLOPs per SURVEY.md 8(d): "
                                  "for the BVH kernels the sphere term is 32/box test + 25|31/leaf test from device counters, so frac is the "
-                                 "share of peak spent on algorithmically necessary FP32 work; brute_force_equivalent prices the same samples/s "
-                                 "with the brute-force formula (work the BVH avoids, not work done)"},
+                                 "share of peak spent on algorithmically necessary FP32 work; brute_force_kernel is the measured figure of "
+                                 "the brute-force formulation 8(d) prices (its own FLOPs over its own time)"},
         }
         if world == 1 and args.cpu_spp > 0:
-            threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+            threads, host = host_threads()
             out["cpu_baseline"] = cpu_baseline(args.scene, w, h, depth, args.cpu_spp, threads)
+            out["cpu_baseline"]["host"] = host
             out["config"]["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         assert host_img is not None and host_img.shape == (h, w)
         print(json.dumps(out))

@@ -98,6 +98,15 @@ typedef struct pt_params {
 #define PT_FLAG_FORCE_LDS 4u
 #define PT_FLAG_BRUTE_FORCE 8u
 #define PT_FLAG_REPRODUCIBLE 16u
+/* Compatibility mode: answer the sphere query the way the reference does -- its recursive
+ * traversal of ITS tree (src/main.cpp:53-91: exact hit_test per inner node, both children always, no pruning, raw t at
+ * the leaves) with the pairwise combine of src/main.cpp:78-87, which discards a sibling's valid hit when the other
+ * child returns a t <= 0.001 that is smaller.  Needs the reference-topology tree (pt_hip_build_reference_tree; built
+ * with rng_skip = 0 on first use otherwise); scenes of at most PT_REFERENCE_MAX_SPHERES spheres.  Several times slower
+ * than the default; bit-equal to the reference's own query on the same tree (tests/golden q_t / q_obj), and converged
+ * images then meet the reference renderer at its own noise floor (50.6 dB on the book-1 scene, not D1's 44 dB). */
+#define PT_FLAG_REFERENCE_QUERY 32u
+#define PT_REFERENCE_MAX_SPHERES 4192u /* World::objects[4192], src/render_world.h:85 */
 
 typedef struct pt_stats {
     uint64_t samples;       /* width*height*(spp_end-spp_begin) */
@@ -107,7 +116,7 @@ typedef struct pt_stats {
     uint64_t wave_iterations; /* trips of the per-wave segment loop; lane utilisation = segments / (64 * wave_iterations) */
     uint64_t phase_cycles[3]; /* diagnostic builds (-DPT_STAMPS) only: shader cycles in refill / closest-hit / shading; else 0 */
     double kernel_ms;       /* HIP-event time of the render kernel on its stream */
-    uint32_t kernel;        /* 0 = LDS brute force (fast), 1 = BVH in HBM, 2 = LDS brute force (strict), 3 = BVH in LDS */
+    uint32_t kernel;        /* 0 = LDS brute force (fast), 1 = BVH in HBM, 2 = LDS brute force (strict), 3 = BVH in LDS, 4 = reference tree + pairwise combine */
     uint32_t node_bytes;    /* bytes per tree node the BVH kernels read: 64 (float boxes) or 32 (16-bit grid boxes); 0 without a tree */
 } pt_stats;
 
@@ -121,6 +130,24 @@ const char* pt_hip_last_error(pt_ctx* ctx);
 /* Replaces: World/Camera being handed to the workers through ThreadData (src/main.cpp:421-427) and
  * build_bvh_tree (src/main.cpp:402).  Copies the scene, lays it out for the device, builds the BVH if needed. */
 int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* scene);
+
+/* Replaces: build_bvh_tree (src/main.cpp:131-159, called at src/main.cpp:402) in the reference's own recipe, for
+ * PT_FLAG_REFERENCE_QUERY: random axis per node from the main thread's std::mt19937 stream (src/utils.h:38-63), in-place
+ * first-pivot quicksort of the sub-range (src/main.cpp:93-129), midpoint split, swept leaf boxes.  rng_skip = number of
+ * random_f32 draws the caller's scene construction took from that stream before the build (the reference builds the
+ * tree right after init_test_scene_N on the same thread, src/main.cpp:396-402); 0 = a fresh stream, which is what the
+ * fixtures under tests/golden were generated with.  Call after pt_hip_upload_scene; PT_ERR_UNSUPPORTED beyond
+ * PT_REFERENCE_MAX_SPHERES spheres. */
+int pt_hip_build_reference_tree(pt_ctx* ctx, uint32_t rng_skip);
+/* Host-only (touches no device): the same tree for inspection / export -- the reference-topology exporter of SURVEY.md
+ * 8f rank 2.  Nodes in the order the reference allocates them (children before their parent, the root last):
+ * boxes6[6*i] = Rect3f{pos.xyz, halfWidth, halfHeight, halfLength} (src/geometry.h:31-52), links3[3*i] = {left, right,
+ * object} as node / sphere indices into the CALLER's arrays, -1 for none; order[k] = index of the sphere that the
+ * reference's in-place sorts leave at position k of World::objects (n_spheres entries).  Any output may be NULL.
+ * Returns the node count 2*n_spheres - 1 (outputs are written only if it is <= cap_nodes), 0 on invalid input or more
+ * than PT_REFERENCE_MAX_SPHERES spheres. */
+uint32_t pt_reference_bvh(const pt_scene_desc* scene, uint32_t rng_skip, uint32_t cap_nodes, float* boxes6, int32_t* links3,
+                          uint32_t* order, uint32_t* depth_out);
 
 /* Replaces: the thread-pool submit + join over all 32x32 blocks (src/main.cpp:415-477).
  * accum_rgba_host: width*height*4 floats, row-major top-down like Image.pixels (src/image.h:11-14); receives the
@@ -149,6 +176,29 @@ int pt_hip_render_device(pt_ctx* ctx, const pt_params* params, float* accum_rgba
  * pt_hip_render_device for the concurrent ones); pt_hip_last_stats after it reads the shared array, so take the
  * statistics before the next static call on that GPU.  accum_rgba_dev and params as for pt_hip_render_device. */
 int pt_hip_render_device_static(pt_ctx* ctx, const pt_params* params, float* accum_rgba_dev, void* stream);
+
+/* ---- one node, several GPUs --------------------------------------------------------------- */
+/* Replaces: the thread-pool submit + join (src/main.cpp:448-477) at node scale.  A pt_node owns one pt_ctx, one stream,
+ * one f32 sum buffer and (with more than one GPU) one RCCL communicator per GPU, devices 0 .. n_gpus-1, all driven by the
+ * calling host thread.  pt_node_render splits the samples [spp_begin, spp_end) of EVERY pixel into n_gpus contiguous
+ * slices (pt_spp_slice), renders slice g on GPU g (pt_hip_render_device), joins the per-GPU sums with ONE
+ * ncclAllReduce(sum, f32) over xGMI, resolves on device 0 and copies back what was asked for: the f32 sums
+ * (width*height*4, may be NULL) and / or the packed 0xAARRGGBB pixels (width*height, may be NULL).  Synchronous.  The
+ * sample set is that of a one-GPU render of the same range (Philox is keyed by the global sample index); the sums
+ * agree to float summation order.  RCCL is bound at run time: PT_ERR_UNSUPPORTED if n_gpus > 1 and it cannot be found. */
+typedef struct pt_node pt_node;
+int pt_node_create(int n_gpus, pt_node** out);
+int pt_node_upload_scene(pt_node* node, const pt_scene_desc* scene);
+int pt_node_render(pt_node* node, const pt_params* params, float* accum_rgba_host, uint32_t* bgra_host);
+void pt_node_destroy(pt_node* node);
+const char* pt_node_last_error(pt_node* node);
+int pt_node_gpu_count(const pt_node* node);
+pt_ctx* pt_node_ctx(pt_node* node, int gpu);   /* GPU g's context (statistics, reference tree, ...); owned by the node */
+/* The one-call form SURVEY.md 8(b) proposes: create + upload + render + destroy. */
+int pt_hip_render_node(const pt_scene_desc* scene, const pt_params* params, int n_gpus, float* accum_rgba_host);
+/* Host-only helper: the slice of the samples [spp_begin, spp_end) that part `part` of `n_parts` renders -- contiguous,
+ * disjoint, covering, sizes differing by at most one. */
+void pt_spp_slice(uint32_t spp_begin, uint32_t spp_end, uint32_t n_parts, uint32_t part, uint32_t* out_begin, uint32_t* out_end);
 
 /* Statistics of the last render on this context (synchronises with it). */
 int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out);

@@ -16,17 +16,20 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
 PT_OK = 0
 PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_UNSUPPORTED, PT_ERR_IO = -1, -2, -3, -4, -5, -6
 MAT_NONE, MAT_DIFFUSE, MAT_METAL, MAT_DIALECTRIC = 0, 1, 2, 3
-FLAG_STRICT_SEARCH, FLAG_FORCE_BVH, FLAG_FORCE_LDS, FLAG_BRUTE_FORCE, FLAG_REPRODUCIBLE = 1, 2, 4, 8, 16
+FLAG_STRICT_SEARCH, FLAG_FORCE_BVH, FLAG_FORCE_LDS, FLAG_BRUTE_FORCE, FLAG_REPRODUCIBLE, FLAG_REFERENCE_QUERY = 1, 2, 4, 8, 16, 32
+REFERENCE_MAX_SPHERES = 4192
 PRIM_MISS = -(2 ** 31)
 
 # Every symbol include/pt_hip.h declares (tests/test_abi.py checks the library exports exactly these).
 EXPORTS = (
     "pt_hip_device_count", "pt_hip_create", "pt_hip_destroy", "pt_hip_strerror", "pt_hip_last_error",
-    "pt_hip_upload_scene", "pt_hip_render", "pt_hip_render_device", "pt_hip_render_device_static", "pt_hip_last_stats", "pt_hip_debug_counters", "pt_chunk_schedule", "pt_bvh_selfcheck", "pt_hip_resolve_device",
+    "pt_hip_upload_scene", "pt_hip_build_reference_tree", "pt_reference_bvh", "pt_hip_render", "pt_hip_render_device", "pt_hip_render_device_static", "pt_hip_last_stats", "pt_hip_debug_counters", "pt_chunk_schedule", "pt_bvh_selfcheck", "pt_hip_resolve_device",
     "pt_resolve", "pt_pack_bgra", "pt_bmp_write", "pt_bmp_write_bgra", "pt_bmp_header",
     "pt_scene_builtin", "pt_scene_get_desc", "pt_scene_free", "pt_scene_save", "pt_scene_load",
     "pt_hip_probe_primitives", "pt_hip_probe_hits", "pt_hip_probe_get_rays", "pt_hip_probe_scatter", "pt_hip_probe_paths",
     "pt_hip_probe_samples", "pt_hip_probe_philox",
+    "pt_node_create", "pt_node_upload_scene", "pt_node_render", "pt_node_destroy", "pt_node_last_error", "pt_node_gpu_count", "pt_node_ctx",
+    "pt_hip_render_node", "pt_spp_slice",
 )
 
 
@@ -90,6 +93,9 @@ def load_library(path=LIB_PATH):
     L.pt_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.pt_hip_destroy.argtypes = [C.c_void_p]
     L.pt_hip_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+    L.pt_hip_build_reference_tree.argtypes = [C.c_void_p, C.c_uint32]
+    L.pt_reference_bvh.argtypes = [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+    L.pt_reference_bvh.restype = C.c_uint32
     L.pt_hip_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p]
     L.pt_hip_render_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]
     L.pt_hip_render_device_static.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]
@@ -100,6 +106,18 @@ def load_library(path=LIB_PATH):
     L.pt_bvh_selfcheck.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.pt_bvh_selfcheck.restype = C.c_int
     L.pt_hip_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pt_node_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.pt_node_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+    L.pt_node_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]
+    L.pt_node_destroy.argtypes = [C.c_void_p]
+    L.pt_node_last_error.argtypes = [C.c_void_p]
+    L.pt_node_last_error.restype = C.c_char_p
+    L.pt_node_gpu_count.argtypes = [C.c_void_p]
+    L.pt_node_ctx.argtypes = [C.c_void_p, C.c_int]
+    L.pt_node_ctx.restype = C.c_void_p
+    L.pt_hip_render_node.argtypes = [C.POINTER(SceneDesc), C.POINTER(Params), C.c_int, C.c_void_p]
+    L.pt_spp_slice.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.pt_spp_slice.restype = None
     _lib = L
     return L
 
@@ -203,6 +221,18 @@ class Scene:
         keys = ("nodes", "depth", "leaves", "largest_leaf", "spheres_in_leaves", "spheres_outside_leaf_box", "grid_boxes_not_enclosing", "bad_references")
         return st, dict(zip(keys, (int(v) for v in out)))
 
+    def reference_bvh(self, rng_skip=0):
+        """Host-only: the reference-topology tree (build_bvh_tree's recipe, include/pt_hip.h: pt_reference_bvh).
+        -> (boxes (nn, 6), links (nn, 3), order (n,), depth); nodes in the reference's allocation order, root last."""
+        n = self.n_spheres
+        nn = max(0, 2 * n - 1)
+        boxes, links, order = np.zeros((nn, 6), np.float32), np.zeros((nn, 3), np.int32), np.zeros(n, np.uint32)
+        depth = C.c_uint32(0)
+        got = load_library().pt_reference_bvh(C.byref(self.desc), rng_skip, nn, _ptr(boxes), _ptr(links), _ptr(order), C.byref(depth))
+        if got != nn:
+            raise PtError(PT_ERR_UNSUPPORTED if n > REFERENCE_MAX_SPHERES else PT_ERR_INVALID, "pt_reference_bvh")
+        return boxes, links, order, int(depth.value)
+
     def save(self, path):
         st = load_library().pt_scene_save(C.byref(self.desc), os.fsencode(path))
         if st != PT_OK:
@@ -249,6 +279,11 @@ class Renderer:
     def upload(self, scene: Scene):
         self._check(self.L.pt_hip_upload_scene(self.h, C.byref(scene.desc)), "pt_hip_upload_scene")
         self.scene = scene
+
+    def build_reference_tree(self, rng_skip=0):
+        """The reference-topology tree PT_FLAG_REFERENCE_QUERY traverses (rng_skip: draws taken from the main thread's
+        MT19937 stream before build_bvh_tree)."""
+        self._check(self.L.pt_hip_build_reference_tree(self.h, rng_skip), "pt_hip_build_reference_tree")
 
     @staticmethod
     def params(width, height, spp_begin, spp_end, max_depth, seed=0, flags=0):
@@ -340,6 +375,58 @@ class Renderer:
         out = np.zeros(n, np.uint32)
         self._check(self.L.pt_hip_probe_philox(self.h, C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_uint32(n), _ptr(out)), "pt_hip_probe_philox")
         return out
+
+
+class Node:
+    """pt_node: every GPU of one node behind one handle -- spp split + one RCCL all-reduce inside the library."""
+
+    def __init__(self, n_gpus):
+        self.L = load_library()
+        h = C.c_void_p()
+        st = self.L.pt_node_create(n_gpus, C.byref(h))
+        if st != PT_OK:
+            raise PtError(st, f"pt_node_create({n_gpus})")
+        self.h, self.n = h, n_gpus
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pt_node_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, st, what):
+        if st != PT_OK:
+            raise PtError(st, what, self.L.pt_node_last_error(self.h).decode())
+
+    def upload(self, scene: Scene):
+        self._check(self.L.pt_node_upload_scene(self.h, C.byref(scene.desc)), "pt_node_upload_scene")
+
+    def render(self, width, height, spp_begin, spp_end, max_depth, seed=0, flags=0, want_bgra=False):
+        """-> (height, width, 4) f32 sums over the whole sample range [, (height, width) uint32 0xAARRGGBB]."""
+        out = np.empty((height, width, 4), np.float32)
+        bgra = np.empty((height, width), np.uint32) if want_bgra else None
+        p = Params(width, height, spp_begin, spp_end, max_depth, flags, seed)
+        self._check(self.L.pt_node_render(self.h, C.byref(p), _ptr(out), _ptr(bgra)), "pt_node_render")
+        return (out, bgra) if want_bgra else out
+
+    def stats(self, gpu=0):
+        s = Stats()
+        st = self.L.pt_hip_last_stats(C.c_void_p(self.L.pt_node_ctx(self.h, gpu)), C.byref(s))
+        if st != PT_OK:
+            raise PtError(st, "pt_hip_last_stats")
+        return {k: getattr(s, k) for k, _ in Stats._fields_ if k != "phase_cycles"}
+
+
+def spp_slice(spp_begin, spp_end, n_parts, part):
+    """Host-only: the sample slice of part `part` of `n_parts` (pt_spp_slice)."""
+    a, b = C.c_uint32(), C.c_uint32()
+    load_library().pt_spp_slice(spp_begin, spp_end, n_parts, part, C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 # ---- host-only helpers (no GPU needed) -----------------------------------------------------------------------

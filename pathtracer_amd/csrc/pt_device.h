@@ -446,9 +446,15 @@ PT_DEV bool box_hit_cone(float lox, float loy, float loz, float hix, float hiy, 
     return cone_planes(lox, hix, loy, hiy, loz, hiz, r1x, r1y, r1z, n1x, n1y, n1z, r2x, r2y, r2z, n2x, n2y, n2z, best, tnear);
 }
 
+// The reference-topology tree of PT_FLAG_REFERENCE_QUERY (host: pt_reference_bvh; 32 bytes per node in HBM):
+//   n0 = {box centre xyz, halfWidth}   n1 = {halfHeight, halfLength, bits(left), bits(right)}      (Rect3f, geometry.h:31-52)
+//   leaf: right = 0xFFFFFFFF and left = the sphere's SLOT in BvhView::sph / vel / mat.
+struct RefView { const float4* nodes; uint32_t root, n_nodes; };
+constexpr uint32_t kRefLeaf = 0xFFFFFFFFu;
+
 struct QueryCtx // per-lane scratch and counters of the sphere query
 {
-    BvhView bvh; uint32_t* stack; uint32_t searched, nodeVisits, sphereTests, leafBatch;
+    BvhView bvh; RefView ref; uint32_t* stack; uint32_t searched, nodeVisits, sphereTests, leafBatch;
 #ifdef PT_STAMPS
     uint32_t innerIters, leafIters;              // wave-level trips through the two kinds of traversal step
     unsigned long long cycInner, cycLeaf;        // s_memtime spent in them
@@ -664,7 +670,7 @@ template <bool MOVING> PT_DEV V3 trav_centre(const BvhView& b, int32_t slot, flo
 struct Hit { float t; int32_t prim; V3 point, normal; Material m; };
 
 // How the sphere query is answered.
-enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2, MODE_BVH_LDS = 3, MODE_BVH_Q = 4 };
+enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2, MODE_BVH_LDS = 3, MODE_BVH_Q = 4, MODE_REF = 5 };
 constexpr bool mode_is_bvh(int m) { return m == MODE_BVH || m == MODE_BVH_LDS || m == MODE_BVH_Q; }
 constexpr bool mode_in_hbm(int m) { return m == MODE_BVH || m == MODE_BVH_Q; } // BVH / BVH_Q: tree read from HBM; BVH_LDS: tree staged in LDS
 // Which traversals test boxes against a cone around the ray (box_hit_cone): all of them.  The cone is what makes the
@@ -675,6 +681,103 @@ constexpr bool mode_uses_cone(int m) { return mode_in_hbm(m); }
 #else
 constexpr bool mode_uses_cone(int m) { return mode_is_bvh(m); }
 #endif
+
+// ------------------------------------------------------------------ the reference's own query (PT_FLAG_REFERENCE_QUERY)
+// hit_test(Ray, Rect3f) (geometry.cpp:83-115) in the reference's arithmetic: here the box test decides the RESULT (a
+// subtree whose box is missed contributes "no hit", and the pairwise combine below turns that into discarded hits), so
+// it is restated operation by operation, contraction off, correctly rounded divides, `<`-ternary MIN / MAX (types.h:12-13)
+// with their NaN behaviour (a zero direction component gives 0 * inf).
+PT_DEV bool ref_hit_test(const Ray& ray, float px, float py, float pz, float hw, float hh, float hl)
+{
+    float inverseDirX = 1.0f / ray.d.x;
+    float tx0 = ((px - hw) - ray.o.x) * inverseDirX;
+    float tx1 = ((px + hw) - ray.o.x) * inverseDirX;
+    if (tx0 > tx1) { float c = tx0; tx0 = tx1; tx1 = c; }
+    float inverseDirY = 1.0f / ray.d.y;
+    float ty0 = ((py - hh) - ray.o.y) * inverseDirY;
+    float ty1 = ((py + hh) - ray.o.y) * inverseDirY;
+    if (ty0 > ty1) { float c = ty0; ty0 = ty1; ty1 = c; }
+    float inverseDirZ = 1.0f / ray.d.z;
+    float tz0 = ((pz - hl) - ray.o.z) * inverseDirZ;
+    float tz1 = ((pz + hl) - ray.o.z) * inverseDirZ;
+    if (tz0 > tz1) { float c = tz0; tz0 = tz1; tz1 = c; }
+    const float mxy = tx0 < ty0 ? ty0 : tx0, tMin = mxy < tz0 ? tz0 : mxy; // MAX_VALUE(MAX_VALUE(tx0, ty0), tz0)
+    const float nxy = tx1 < ty1 ? tx1 : ty1, tMax = nxy < tz1 ? nxy : tz1; // MIN_VALUE(MIN_VALUE(tx1, ty1), tz1)
+    return !(tMin >= tMax);
+}
+// intersection_test(Ray, BVH*, time, &obj) (main.cpp:53-91) without the recursion: every lane walks the reference's
+// call tree with an explicit stack of the calls that wait for a child (two dwords per level in LDS, lane-strided:
+// {node | second child under way << 31, t of the left child} and the left child's sphere slot + 1).  A leaf returns the
+// RAW near-root t of its sphere (no box test, may be <= 0.001 or negative); an inner node whose box is hit asks BOTH
+// children, always, and combines: left iff tLeft < tRight && tLeft > MIN_T, else right iff tRight < tLeft && tRight >
+// MIN_T, else no hit -- so a child that returns a small invalid t hides its sibling's valid one (the quirk).
+// Returns t and the winner's sphere slot (-1: none).  Stack: 3 dwords x (tree depth + 1) per lane.
+template <bool MOVING> PT_DEV float ref_query(const QueryCtx& qc, const Ray& ray, float time, bool live, int32_t* slotOut, uint32_t* boxTests, uint32_t* sphereTests)
+{
+    const RefView& rv = qc.ref;
+    uint32_t* const stack = qc.stack;
+    uint32_t level = 0;                       // calls waiting for a child
+    uint32_t enter = rv.root;                 // node to call next; kRefLeaf = a call has just returned (tRet, sRet)
+    float tRet = kF32Max; int32_t sRet = -1;
+    bool done = !live || rv.n_nodes == 0;
+    for (;;)
+    {
+        if (pt_ballot(!done) == 0ull) break;
+        if (!done)
+        {
+            if (enter != kRefLeaf)
+            {
+                const float4 n1 = rv.nodes[2 * enter + 1];
+                const uint32_t left = __float_as_uint(n1.z), right = __float_as_uint(n1.w);
+                if (right == kRefLeaf)                                    // main.cpp:61-69
+                {
+                    const float4 sd = qc.bvh.sph[left];
+                    V3 c = v3(sd.x, sd.y, sd.z);
+                    if (MOVING) { const float4 vd = qc.bvh.vel[left]; c = add(c, mul(v3(vd.x, vd.y, vd.z), time)); } // main.cpp:66
+                    tRet = intersect_sphere_exact(ray, c, sd.w);
+                    sRet = (int32_t)left;
+                    enter = kRefLeaf;
+                    *sphereTests += 1u;
+                }
+                else
+                {
+                    const float4 n0 = rv.nodes[2 * enter];
+                    *boxTests += 1u;
+                    if (ref_hit_test(ray, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y))   // main.cpp:70
+                    {
+                        stack[(3u * level) * 64u] = enter;                 // first child under way
+                        ++level;
+                        enter = left;                                       // main.cpp:75
+                    }
+                    else { tRet = kF32Max; sRet = -1; enter = kRefLeaf; }
+                }
+            }
+            else if (level == 0u)
+                done = true;
+            else
+            {
+                uint32_t* f = stack + (3u * (level - 1u)) * 64u;
+                const uint32_t head = f[0];
+                if (!(head & 0x80000000u))                                 // the left child has returned: ask the right one (main.cpp:76)
+                {
+                    f[0] = head | 0x80000000u; f[64] = __float_as_uint(tRet); f[128] = (uint32_t)(sRet + 1);
+                    enter = __float_as_uint(rv.nodes[2 * head + 1].w);
+                }
+                else                                                        // both are back: main.cpp:78-87
+                {
+                    const float tLeft = __uint_as_float(f[64]), tRight = tRet;
+                    const int32_t sLeft = (int32_t)f[128] - 1;
+                    if (tLeft < tRight && tLeft > kMinT) { tRet = tLeft; sRet = sLeft; }
+                    else if (tRight < tLeft && tRight > kMinT) { /* tRet, sRet stay the right child's */ }
+                    else { tRet = kF32Max; sRet = -1; }
+                    --level;
+                }
+            }
+        }
+    }
+    *slotOut = sRet;
+    return tRet;
+}
 
 // First half of cast_ray (main.cpp:180-216): planes linearly, then the sphere query; closest wins, planes win ties.
 // plane loop (main.cpp:186-200): closest plane hit, or kF32Max / -1
@@ -738,6 +841,19 @@ template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, cons
         trav_begin(q.bvh, planeT, planeIdx, live, q, ts);
         bvh_run<MOVING, mode_uses_cone(MODE), MODE == MODE_BVH_Q>(q.bvh, ray, time, live, q, ts, 0u);
         return make_hit_bvh<MOVING>(s, ray, time, q, ts);
+    }
+    if (MODE == MODE_REF)
+    {
+        // main.cpp:203-216 on the reference's tree: t must still beat the closest plane, strictly
+        int32_t slot = -1;
+        uint32_t boxTests = 0, sphereTests = 0;
+        const float t = ref_query<MOVING>(q, ray, time, live, &slot, &boxTests, &sphereTests);
+        for (int o = 32; o > 0; o >>= 1) { boxTests += __shfl_xor(boxTests, o); sphereTests += __shfl_xor(sphereTests, o); }
+        q.nodeVisits += boxTests; q.sphereTests += sphereTests;
+        Material m; m.type = MAT_NONE; m.colour = v4(0, 0, 0, 0); m.roughness = 0; m.n = 0;
+        uint32_t orig = 0;
+        if (slot >= 0) { m = load_material(q.bvh.mat, (uint32_t)slot); orig = __float_as_uint(q.bvh.mat[2 * (uint32_t)slot].w); }
+        return make_hit(s, ray, slot, t, trav_centre<MOVING>(q.bvh, slot, time), m, orig, planeIdx, planeT);
     }
     int32_t obj;
     float t = kF32Max;

@@ -43,6 +43,7 @@ struct SceneArgs
     uint32_t leaf_batch;    // lanes that must wait at a leaf before the wave runs the leaf code (BVH modes)
     uint32_t refill_min;
     uint32_t exit_lanes;    // a trip's traversal phase is left once fewer lanes than this still traverse and one is ready to shade
+    RefView ref;            // MODE_REF: the reference-topology tree (PT_FLAG_REFERENCE_QUERY)
 };
 
 // LDS carve-up behind the scene image: per wave, [64 pixels x rgba] accumulators (render kernel) and, in the BVH modes,
@@ -56,6 +57,7 @@ template <int MODE> __device__ __forceinline__ QueryCtx make_query(const SceneAr
         q.bvh.nodes = smem + a.bvh_off[0]; q.bvh.sph = smem + a.bvh_off[1]; q.bvh.vel = smem + a.bvh_off[2];
         if (a.bvh_off[3] != 0xFFFFFFFFu) q.bvh.mat = smem + a.bvh_off[3]; // else: materials stay in HBM (touched once per hit)
     }
+    q.ref = a.ref;
     q.stack = stackBase; q.searched = 0; q.nodeVisits = 0; q.sphereTests = 0; q.leafBatch = a.leaf_batch;
 #ifdef PT_STAMPS
     q.innerIters = 0; q.leafIters = 0; q.cycInner = 0; q.cycLeaf = 0;
@@ -322,8 +324,8 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     {
         unsigned long long* slot = a.stats + kStatWords * (1u + waveId);
         slot[0] = segs; slot[1] = iters; slot[5] = qc.searched;
-        slot[6] = mode_is_bvh(MODE) ? qc.nodeVisits : 0u; // both tallies are wave-level already
-        slot[7] = mode_is_bvh(MODE) ? qc.sphereTests : 0u;
+        slot[6] = (mode_is_bvh(MODE) || MODE == MODE_REF) ? qc.nodeVisits : 0u; // both tallies are wave-level already
+        slot[7] = (mode_is_bvh(MODE) || MODE == MODE_REF) ? qc.sphereTests : 0u;
 #ifdef PT_STAMPS
         slot[2] = cyc_refill; slot[3] = cyc_hit; slot[4] = cyc_shade;
         slot[9] = qc.innerIters; slot[10] = qc.leafIters; slot[11] = qc.cycInner; slot[12] = qc.cycLeaf;
@@ -381,7 +383,7 @@ template <bool MOVING, int MODE, bool CARRY> RenderKernel render_kernel_for(bool
 {
     if constexpr (MODE == MODE_BVH_LDS) return resume ? &k_render_w7<MOVING, MODE, true, CARRY> : &k_render_w7<MOVING, MODE, false, CARRY>;
     else if constexpr (mode_in_hbm(MODE)) return resume ? &k_render_w6<MOVING, MODE, true, CARRY> : &k_render_w6<MOVING, MODE, false, CARRY>;
-    else if constexpr (MODE == MODE_LDS_STRICT) return &k_render<MOVING, MODE, CARRY>;
+    else if constexpr (MODE == MODE_LDS_STRICT || MODE == MODE_REF) return &k_render<MOVING, MODE, CARRY>; // test / compatibility modes: left to the compiler
     else return &k_render_w6<MOVING, MODE, false, CARRY>;
 }
 template <bool MOVING, bool CARRY> RenderKernel render_kernel_mc(int mode, bool resume)
@@ -390,6 +392,7 @@ template <bool MOVING, bool CARRY> RenderKernel render_kernel_mc(int mode, bool 
     if (mode == MODE_BVH) return render_kernel_for<MOVING, MODE_BVH, CARRY>(resume);
     if (mode == MODE_BVH_Q) return render_kernel_for<MOVING, MODE_BVH_Q, CARRY>(resume);
     if (mode == MODE_LDS_STRICT) return render_kernel_for<MOVING, MODE_LDS_STRICT, CARRY>(resume);
+    if (mode == MODE_REF) return render_kernel_for<MOVING, MODE_REF, CARRY>(resume);
     return render_kernel_for<MOVING, MODE_LDS_FAST, CARRY>(resume);
 }
 static RenderKernel render_kernel(bool moving, int mode, bool resume, bool carry)
@@ -551,7 +554,11 @@ struct pt_ctx
     float4* blob_dev = nullptr; float4* blob_planes_dev = nullptr; float4* blob_bvh_dev = nullptr; // brute-force image, planes only, planes + tree
     float4* nodes_dev = nullptr; float4* sph_dev = nullptr; float4* vel_dev = nullptr; float4* mat_dev = nullptr;
     uint32_t bvh_nodes = 0, bvh_depth = 0;
-    SceneArgs sc_lds{}, sc_bvh{}, sc_bvh_lds{};
+    SceneArgs sc_lds{}, sc_bvh{}, sc_bvh_lds{}, sc_ref{};
+    pt_scene_desc desc{};                       // the uploaded scene's description: COPIES of the caller's arrays (below), for pt_hip_build_reference_tree
+    std::vector<float> h_pos_r, h_vel;
+    std::vector<uint32_t> slot_of_sphere;       // caller's sphere index -> slot in sph_dev / vel_dev / mat_dev (leaf order of the own tree)
+    float4* ref_nodes_dev = nullptr; bool has_ref = false;
     float* accum_dev = nullptr; size_t accum_floats = 0;
     float* partial_dev = nullptr; size_t partial_floats = 0; // per-chunk sums of a chunked launch (grown on demand, kept)
     int num_cus = 0;
@@ -568,6 +575,8 @@ struct pt_ctx
     struct Occ { const void* kern; int block; size_t lds; int wgs; };
     std::vector<Occ> occ;   // answers of the occupancy query (render_occupancy)
 };
+
+extern "C" int pt_hip_build_reference_tree(pt_ctx* ctx, uint32_t rng_skip);
 
 namespace {
 
@@ -630,6 +639,14 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
 {
     const bool brute = (flags & (PT_FLAG_BRUTE_FORCE | PT_FLAG_STRICT_SEARCH)) != 0;
     if ((flags & PT_FLAG_FORCE_BVH) && ((flags & PT_FLAG_FORCE_LDS) || brute)) return PT_ERR_UNSUPPORTED;
+    if (flags & PT_FLAG_REFERENCE_QUERY)
+    {
+        if (brute || (flags & (PT_FLAG_FORCE_BVH | PT_FLAG_FORCE_LDS))) return PT_ERR_UNSUPPORTED;
+        if (!ctx->has_ref) { int st = pt_hip_build_reference_tree(ctx, 0); if (st != PT_OK) return st; }
+        *mode = MODE_REF; *sc = &ctx->sc_ref;
+        *lds = (size_t)(*sc)->blob_f4 * 16 + waves * ((acc ? kAccBytesPerWave : 0) + (size_t)(*sc)->stack_entries * 64 * 4);
+        return *lds > ctx->lds_limit ? PT_ERR_UNSUPPORTED : PT_OK;
+    }
     if (brute)
     {
         if (!ctx->lds_ok) return PT_ERR_UNSUPPORTED;
@@ -652,8 +669,8 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
     do {                                                                                                        \
         int st_ = PT_OK;                                                                                        \
         auto go_ = [&](auto kern) { st_ = set_lds(ctx, kern, lds); if (st_ == PT_OK) hipLaunchKernelGGL(kern, grid, block, lds, stream, args); }; \
-        if (moving) { if (mode == MODE_BVH_LDS) go_(KERNEL<true, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<true, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<true, MODE_BVH_Q>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<true, MODE_LDS_STRICT>); else go_(KERNEL<true, MODE_LDS_FAST>); } \
-        else        { if (mode == MODE_BVH_LDS) go_(KERNEL<false, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<false, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<false, MODE_BVH_Q>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<false, MODE_LDS_STRICT>); else go_(KERNEL<false, MODE_LDS_FAST>); } \
+        if (moving) { if (mode == MODE_BVH_LDS) go_(KERNEL<true, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<true, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<true, MODE_BVH_Q>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<true, MODE_LDS_STRICT>); else if (mode == MODE_REF) go_(KERNEL<true, MODE_REF>); else go_(KERNEL<true, MODE_LDS_FAST>); } \
+        else        { if (mode == MODE_BVH_LDS) go_(KERNEL<false, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<false, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<false, MODE_BVH_Q>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<false, MODE_LDS_STRICT>); else if (mode == MODE_REF) go_(KERNEL<false, MODE_REF>); else go_(KERNEL<false, MODE_LDS_FAST>); } \
         if (st_ != PT_OK) return st_;                                                                           \
     } while (0)
 
@@ -689,6 +706,8 @@ void free_scene(pt_ctx* c)
 {
     float4** ptrs[] = {&c->blob_dev, &c->blob_planes_dev, &c->blob_bvh_dev, &c->nodes_dev, &c->sph_dev, &c->vel_dev, &c->mat_dev};
     for (float4** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (c->ref_nodes_dev) { (void)hipFree(c->ref_nodes_dev); c->ref_nodes_dev = nullptr; }
+    c->has_ref = false;
     c->has_scene = false;
 }
 
@@ -850,6 +869,15 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         if (const char* e = getenv("PT_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->sc_bvh.leaf_batch = (uint32_t)v; } // tuning experiments only
         ctx->bvh_nodes = bv.n_nodes; ctx->bvh_depth = bv.depth;
         ctx->moving = bv.moving;
+        // what pt_hip_build_reference_tree needs later: the spheres as the caller numbered them, and where each one sits now
+        ctx->desc = *d;
+        ctx->h_pos_r.assign(d->sphere_pos_r, d->sphere_pos_r + 4 * (size_t)d->n_spheres);
+        if (d->sphere_vel) ctx->h_vel.assign(d->sphere_vel, d->sphere_vel + 3 * (size_t)d->n_spheres); else ctx->h_vel.clear();
+        ctx->desc.sphere_pos_r = ctx->h_pos_r.data(); ctx->desc.sphere_vel = d->sphere_vel ? ctx->h_vel.data() : nullptr;
+        ctx->desc.sphere_mat_type = nullptr; ctx->desc.sphere_mat_rgba = nullptr; ctx->desc.sphere_mat_param = nullptr;
+        ctx->desc.plane_n_d = nullptr; ctx->desc.plane_mat_type = nullptr; ctx->desc.plane_mat_rgba = nullptr; ctx->desc.plane_mat_param = nullptr;
+        ctx->slot_of_sphere.assign(d->n_spheres, 0u);
+        for (uint32_t slot = 0; slot < bv.n_spheres; ++slot) ctx->slot_of_sphere[pth::f2u(bv.mat[8 * (size_t)slot + 3])] = slot;
         if (bv.depth + 1 > kBvhStack) { ctx->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
         // (3) the same tree staged in LDS behind the planes, when planes + tree + payload + 4 waves' stacks fit
         const uint32_t entries = ctx->sc_bvh.stack_entries;
@@ -880,6 +908,42 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         }
     }
     ctx->has_scene = true;
+    return PT_OK;
+}
+
+int pt_hip_build_reference_tree(pt_ctx* ctx, uint32_t rng_skip)
+{
+    int st = check_scene(ctx);
+    if (st != PT_OK) return st;
+    const uint32_t n = ctx->desc.n_spheres;
+    if (n > PT_REFERENCE_MAX_SPHERES) { ctx->err = "PT_FLAG_REFERENCE_QUERY: more spheres than the reference's World holds (4192)"; return PT_ERR_UNSUPPORTED; }
+    Bind b(ctx);
+    if (ctx->ref_nodes_dev) { (void)hipFree(ctx->ref_nodes_dev); ctx->ref_nodes_dev = nullptr; }
+    ctx->has_ref = false;
+    ctx->sc_ref = ctx->sc_bvh;                       // planes-only LDS image; spheres, velocities, materials in HBM (slot order)
+    ctx->sc_ref.exit_lanes = 0;
+    ctx->sc_ref.ref = RefView{nullptr, 0u, 0u};
+    uint32_t depth = 0;
+    if (n != 0)
+    {
+        const uint32_t nn = 2u * n - 1u;
+        std::vector<float> boxes(6 * (size_t)nn); std::vector<int32_t> links(3 * (size_t)nn);
+        if (pt_reference_bvh(&ctx->desc, rng_skip, nn, boxes.data(), links.data(), nullptr, &depth) != nn) return PT_ERR_INVALID;
+        std::vector<float> img(8 * (size_t)nn);
+        for (uint32_t i = 0; i < nn; ++i)
+        {
+            const float* bx = boxes.data() + 6 * (size_t)i; const int32_t* lk = links.data() + 3 * (size_t)i;
+            float* o = img.data() + 8 * (size_t)i;
+            o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2]; o[3] = bx[3]; o[4] = bx[4]; o[5] = bx[5];
+            const bool leaf = lk[2] >= 0;
+            o[6] = pth::u2f(leaf ? ctx->slot_of_sphere[(size_t)lk[2]] : (uint32_t)lk[0]);
+            o[7] = pth::u2f(leaf ? kRefLeaf : (uint32_t)lk[1]);
+        }
+        st = upload_f4(ctx, img.data(), img.size() * 4, &ctx->ref_nodes_dev); if (st != PT_OK) return st;
+        ctx->sc_ref.ref = RefView{ctx->ref_nodes_dev, nn - 1u, nn};  // the root is allocated last (main.cpp:152)
+    }
+    ctx->sc_ref.stack_entries = 3u * (depth + 1u);   // ref_query: three dwords per waiting call
+    ctx->has_ref = true;
     return PT_OK;
 }
 
@@ -1028,7 +1092,7 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
     ctx->last_mode = mode;
     ctx->last = pt_stats{};
     ctx->last.samples = (uint64_t)p->width * p->height * a.nspp;
-    ctx->last.kernel = mode_in_hbm(mode) ? 1u : mode == MODE_BVH_LDS ? 3u : mode == MODE_LDS_STRICT ? 2u : 0u;
+    ctx->last.kernel = mode_in_hbm(mode) ? 1u : mode == MODE_BVH_LDS ? 3u : mode == MODE_LDS_STRICT ? 2u : mode == MODE_REF ? 4u : 0u;
     ctx->last.node_bytes = mode == MODE_BVH_Q ? 32u : mode_is_bvh(mode) ? 64u : 0u;
     return PT_OK;
 }
@@ -1076,9 +1140,9 @@ int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out)
     ctx->last.segments = st[0];
     ctx->last.wave_iterations = st[1];
     ctx->last.phase_cycles[0] = st[2]; ctx->last.phase_cycles[1] = st[3]; ctx->last.phase_cycles[2] = st[4];
-    if (mode_is_bvh(ctx->last_mode))
+    if (mode_is_bvh(ctx->last_mode) || ctx->last_mode == MODE_REF)
     {
-        ctx->last.node_visits = st[6];   // inner nodes fetched (two box tests each)
+        ctx->last.node_visits = st[6];   // inner nodes fetched (two box tests each; reference tree: one hit_test each)
         ctx->last.sphere_tests = st[7];  // exact leaf tests
     }
     else

@@ -2,16 +2,13 @@
 // libpt_hip.so.  What the reference fixes at compile time -- image size, SAMPLES_PER_PIXEL, MAX_RAY_DEPTH
 // (src/main.cpp:29-42), the scene call (src/main.cpp:396), the output name (src/main.cpp:487) -- are options here;
 // the flow is the same: build the scene, time the "PathTracing" span (src/main.cpp:412-481), resolve, write the BMP.
-// Several GPUs: one host thread and one pt_ctx per device, each renders a contiguous slice of the sample range
-// (SURVEY.md 8e); the slices are summed on the host in device order before the resolve.  (The RCCL all-reduce variant
-// of the same split is pathtracer_amd/distributed.py; this tool stays free of a communicator so that it links against
-// nothing but libpt_hip.so.)
+// Several GPUs: pt_node_* -- one pt_ctx, stream and RCCL communicator per device; each renders a contiguous slice of the
+// sample range, one ncclAllReduce(sum) joins the f32 sums on the devices, device 0 resolves and packs.
 #include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/pt_hip.h"
@@ -22,7 +19,7 @@ struct Options
 {
     int scene = 1; uint32_t n5 = 100000; std::string sceneFile, saveScene, out = "output.bmp";
     uint32_t width = 800, height = 450, spp = 32, depth = 5, flags = 0; // the reference's defaults (src/main.cpp:29-42)
-    uint64_t seed = 0; int gpus = 1;
+    uint64_t seed = 0; int gpus = 1; uint32_t rngSkip = 0;
 };
 
 void usage()
@@ -30,7 +27,9 @@ void usage()
     fprintf(stderr,
             "usage: pt_render [--scene 1|2|3|4|5] [--spheres N (scene 5)] [--scene-file FILE] [--save-scene FILE]\n"
             "                 [--width W] [--height H] [--spp S] [--depth D] [--seed N] [--gpus G] [--flags F] [--out FILE.bmp]\n"
-            "  scenes 1-3: the reference's init_test_scene_1/2/3; 4: materials + depth of field; 5: N random spheres\n");
+            "                 [--reference-query [--rng-skip N]]\n"
+            "  scenes 1-3: the reference's init_test_scene_1/2/3; 4: materials + depth of field; 5: N random spheres\n"
+            "  --reference-query: the reference's own BVH (random-axis median split) and pairwise-combine traversal\n");
 }
 
 bool parse(int argc, char** argv, Options* o)
@@ -52,6 +51,8 @@ bool parse(int argc, char** argv, Options* o)
         else if (a == "--seed" && next(&v)) o->seed = strtoull(v, nullptr, 10);
         else if (a == "--gpus" && next(&v)) o->gpus = atoi(v);
         else if (a == "--flags" && next(&v)) o->flags = (uint32_t)strtoul(v, nullptr, 0);
+        else if (a == "--reference-query") o->flags |= PT_FLAG_REFERENCE_QUERY;
+        else if (a == "--rng-skip" && next(&v)) o->rngSkip = (uint32_t)strtoul(v, nullptr, 10);
         else if (a == "--out" && next(&v)) o->out = v;
         else { fprintf(stderr, "pt_render: bad argument '%s'\n", a.c_str()); return false; }
     }
@@ -83,54 +84,42 @@ int main(int argc, char** argv)
     if (have < o.gpus) { fprintf(stderr, "pt_render: %d HIP device(s) visible, %d asked for -- there is no CPU fallback\n", have, o.gpus); return 3; }
     if ((uint32_t)o.gpus > o.spp) o.gpus = (int)o.spp;
 
-    // ---- contexts + upload (BVH build; src/main.cpp:402)
+    // ---- the node: one context + stream (+ RCCL communicator) per GPU; upload = BVH build (src/main.cpp:402)
     const auto tUpload = std::chrono::steady_clock::now();
-    std::vector<pt_ctx*> ctx((size_t)o.gpus, nullptr);
-    for (int g = 0; g < o.gpus; ++g)
-    {
-        int st = pt_hip_create(g, &ctx[(size_t)g]);
-        if (st == PT_OK) st = pt_hip_upload_scene(ctx[(size_t)g], &d);
-        if (st != PT_OK) { fprintf(stderr, "pt_render: device %d: %s (%s)\n", g, pt_hip_strerror(st), ctx[(size_t)g] ? pt_hip_last_error(ctx[(size_t)g]) : ""); return 1; }
-    }
+    pt_node* node = nullptr;
+    int st = pt_node_create(o.gpus, &node);
+    if (st != PT_OK) { fprintf(stderr, "pt_render: cannot set up %d GPU(s): %s\n", o.gpus, pt_hip_strerror(st)); return 1; }
+    st = pt_node_upload_scene(node, &d);
+    if (st == PT_OK && (o.flags & PT_FLAG_REFERENCE_QUERY))
+        for (int g = 0; g < o.gpus && st == PT_OK; ++g) st = pt_hip_build_reference_tree(pt_node_ctx(node, g), o.rngSkip);
+    if (st != PT_OK) { fprintf(stderr, "pt_render: %s (%s)\n", pt_hip_strerror(st), pt_node_last_error(node)); return 1; }
     printf("Upload + BVH build on %d GPU(s): %.1f ms\n", o.gpus, ms_since(tUpload));
 
-    // ---- the "PathTracing" span (src/main.cpp:412-481): every device renders its slice of the samples
-    const size_t floats = (size_t)o.width * o.height * 4;
-    std::vector<std::vector<float>> sums((size_t)o.gpus, std::vector<float>(floats));
-    std::vector<int> status((size_t)o.gpus, PT_OK);
-    std::vector<pt_stats> stats((size_t)o.gpus);
+    // ---- the "PathTracing" span (src/main.cpp:412-481): every device renders its slice of the samples, one RCCL
+    // all-reduce joins the f32 sums, device 0 resolves and packs; 4 bytes per pixel come back
+    pt_params p{};
+    p.width = o.width; p.height = o.height; p.max_depth = o.depth; p.flags = o.flags; p.seed = o.seed; p.spp_begin = 0; p.spp_end = o.spp;
+    std::vector<uint32_t> bgra((size_t)o.width * o.height);
     const auto tRender = std::chrono::steady_clock::now();
-    {
-        std::vector<std::thread> workers;
-        for (int g = 0; g < o.gpus; ++g)
-            workers.emplace_back([&, g]() {
-                pt_params p{};
-                p.width = o.width; p.height = o.height; p.max_depth = o.depth; p.flags = o.flags; p.seed = o.seed;
-                p.spp_begin = (uint32_t)((uint64_t)o.spp * (uint64_t)g / (uint64_t)o.gpus);
-                p.spp_end = (uint32_t)((uint64_t)o.spp * (uint64_t)(g + 1) / (uint64_t)o.gpus);
-                status[(size_t)g] = pt_hip_render(ctx[(size_t)g], &p, sums[(size_t)g].data());
-                if (status[(size_t)g] == PT_OK) status[(size_t)g] = pt_hip_last_stats(ctx[(size_t)g], &stats[(size_t)g]);
-            });
-        for (auto& w : workers) w.join();
-    }
-    for (int g = 0; g < o.gpus; ++g)
-        if (status[(size_t)g] != PT_OK) { fprintf(stderr, "pt_render: device %d: %s (%s)\n", g, pt_hip_strerror(status[(size_t)g]), pt_hip_last_error(ctx[(size_t)g])); return 1; }
-    for (int g = 1; g < o.gpus; ++g)
-        for (size_t i = 0; i < floats; ++i) sums[0][i] += sums[(size_t)g][i];
-    std::vector<float> pixels(floats);
-    if (pt_resolve(sums[0].data(), o.width * o.height, o.spp, pixels.data()) != PT_OK) return 1; // src/main.cpp:358
+    st = pt_node_render(node, &p, nullptr, bgra.data());
     const double renderMs = ms_since(tRender);
+    if (st != PT_OK) { fprintf(stderr, "pt_render: %s (%s)\n", pt_hip_strerror(st), pt_node_last_error(node)); return 1; }
     uint64_t samples = 0, segments = 0; double kernelMs = 0;
-    for (int g = 0; g < o.gpus; ++g) { samples += stats[(size_t)g].samples; segments += stats[(size_t)g].segments; if (stats[(size_t)g].kernel_ms > kernelMs) kernelMs = stats[(size_t)g].kernel_ms; }
+    for (int g = 0; g < o.gpus; ++g)
+    {
+        pt_stats s{};
+        if (pt_hip_last_stats(pt_node_ctx(node, g), &s) != PT_OK) continue;
+        samples += s.samples; segments += s.segments; if (s.kernel_ms > kernelMs) kernelMs = s.kernel_ms;
+    }
     printf("PathTracing: Time elapsed: %.3f ms  (%ux%u, %u spp, depth %u: %.1f Msamples/s; kernel %.3f ms, %.3f segments/sample)\n",
            renderMs, o.width, o.height, o.spp, o.depth, (double)samples / renderMs / 1e3, kernelMs, samples ? (double)segments / (double)samples : 0.0);
 
     // ---- output (src/main.cpp:487)
     const auto tWrite = std::chrono::steady_clock::now();
-    const int st = pt_bmp_write(o.out.c_str(), pixels.data(), o.width, o.height);
+    st = pt_bmp_write_bgra(o.out.c_str(), bgra.data(), o.width, o.height);
     if (st != PT_OK) { fprintf(stderr, "pt_render: cannot write %s: %s\n", o.out.c_str(), pt_hip_strerror(st)); return 1; }
     printf("Wrote %s (%.1f ms)\n", o.out.c_str(), ms_since(tWrite));
-    for (pt_ctx* c : ctx) pt_hip_destroy(c);
+    pt_node_destroy(node);
     pt_scene_free(scene);
     return 0;
 }

@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <cmath>
 #include <new>
 
@@ -268,6 +269,99 @@ void flatten(const World& w, const Camera& c, FlatScene* f)
     c.write13(d.camera);
 }
 
+// ------------------------------------------------------------------------------------------------ reference-topology tree
+// build_bvh_tree / sort_render_objects (src/main.cpp:93-159) in the reference's own recipe, for the compatibility mode
+// PT_FLAG_REFERENCE_QUERY: the reference's pairwise-combine query (src/main.cpp:78-87) gives results that depend on
+// the tree's topology, so reproducing its images to the noise floor needs ITS tree -- random axis per node (one
+// random_u32(0,3) for every node, leaves included), in-place sort of the sub-range by centre coordinate at t = 0,
+// split at the midpoint, leaf boxes swept over [startTime, endTime], inner box = union of the children.
+// The reference permutes World::objects in place; here `order` is permuted instead (order[i] = original index of the
+// sphere that ends up at position i), so leaves name spheres of the caller's arrays.
+namespace {
+
+struct RefBox { float px, py, pz, hw, hh, hl; }; // Rect3f (src/geometry.h:31-52): centre + half extents
+
+// Rect3f::from_bounds over the corners of two boxes (src/geometry.cpp:9-31; MIN_VALUE / MAX_VALUE are `<` ternaries, src/types.h:12-13)
+RefBox ref_union(const RefBox& a, const RefBox& b)
+{
+    auto mn = [](float x, float y) { return x < y ? x : y; };
+    auto mx = [](float x, float y) { return x < y ? y : x; };
+    const float minX = mn(a.px - a.hw, b.px - b.hw), maxX = mx(a.px + a.hw, b.px + b.hw);
+    const float minY = mn(a.py - a.hh, b.py - b.hh), maxY = mx(a.py + a.hh, b.py + b.hh);
+    const float minZ = mn(a.pz - a.hl, b.pz - b.hl), maxZ = mx(a.pz + a.hl, b.pz + b.hl);
+    RefBox r;
+    r.px = (minX + maxX) * 0.5f; r.py = (minY + maxY) * 0.5f; r.pz = (minZ + maxZ) * 0.5f;
+    r.hw = (maxX - minX) * 0.5f; r.hh = (maxY - minY) * 0.5f; r.hl = (maxZ - minZ) * 0.5f;
+    return r;
+}
+// bounding_box(Sphere) (src/geometry.cpp:33-37): Rect3f(pos, 2r, 2r, 2r), whose ctor halves the extents again
+RefBox ref_sphere_box(float x, float y, float z, float radius)
+{
+    const float e = radius * 2.0f;
+    return RefBox{x, y, z, e * 0.5f, e * 0.5f, e * 0.5f};
+}
+
+struct RefTreeBuilder
+{
+    const pt_scene_desc* d;
+    pt::HostRng rng;
+    std::vector<uint32_t> order;
+    std::vector<RefBox> boxes;
+    std::vector<int32_t> links; // left, right, object per node
+    uint32_t depth = 0;
+
+    float key(uint32_t pos, uint32_t axis) const { return d->sphere_pos_r[4 * (size_t)order[pos] + axis]; } // SphereObject::pos() at time 0
+    // sort_render_objects (src/main.cpp:93-129): quicksort, first element as pivot, strict `<` partition
+    void sort(uint32_t start, uint32_t end, uint32_t axis)
+    {
+        if (end - start == 1) return;
+        if (end - start == 2)
+        {
+            if (key(start, axis) > key(start + 1, axis)) std::swap(order[start], order[start + 1]);
+            return;
+        }
+        const uint32_t pivot = start;
+        uint32_t split = start + 1;
+        for (uint32_t i = start + 1; i < end; ++i)
+            if (key(i, axis) < key(pivot, axis)) { std::swap(order[i], order[split]); ++split; }
+        std::swap(order[pivot], order[split - 1]);
+        sort(start, split, axis);
+        if (split != end) sort(split, end, axis);
+    }
+    // SphereObject::get_bounding_box (src/render_world.cpp:62-74)
+    RefBox leaf_box(uint32_t orig) const
+    {
+        const float* s = d->sphere_pos_r + 4 * (size_t)orig;
+        const float zero[3] = {0, 0, 0};
+        const float* v = d->sphere_vel ? d->sphere_vel + 3 * (size_t)orig : zero;
+        const RefBox a = ref_sphere_box(s[0] + v[0] * d->t0, s[1] + v[1] * d->t0, s[2] + v[2] * d->t0, s[3]);
+        const RefBox b = ref_sphere_box(s[0] + v[0] * d->t1, s[1] + v[1] * d->t1, s[2] + v[2] * d->t1, s[3]);
+        return ref_union(a, b);
+    }
+    // build_bvh_tree (src/main.cpp:131-159); nodes are appended in the order the reference allocates them (children
+    // first, the root last).  Returns the node's index.
+    int32_t build(uint32_t start, uint32_t end, uint32_t level)
+    {
+        const uint32_t axis = rng.u32(0, 3);
+        if (level > depth) depth = level;
+        if (end - start == 1)
+        {
+            boxes.push_back(leaf_box(order[start]));
+            links.insert(links.end(), {-1, -1, (int32_t)order[start]});
+            return (int32_t)boxes.size() - 1;
+        }
+        sort(start, end, axis);
+        const uint32_t mid = (start + end) / 2;
+        const int32_t l = build(start, mid, level + 1);
+        const int32_t r = build(mid, end, level + 1);
+        boxes.push_back(ref_union(boxes[(size_t)l], boxes[(size_t)r]));
+        links.insert(links.end(), {l, r, -1});
+        return (int32_t)boxes.size() - 1;
+    }
+};
+
+} // namespace
+
 } // namespace pt
 
 // ================================================================================================ C-ABI, host-only part
@@ -290,6 +384,27 @@ pt_scene* pt_scene_builtin(int id, float aspect, uint32_t n_for_id5)
     }
     pt::flatten(s->world, s->camera, &s->flat);
     return s;
+}
+
+uint32_t pt_reference_bvh(const pt_scene_desc* d, uint32_t rng_skip, uint32_t cap_nodes, float* boxes6, int32_t* links3, uint32_t* order, uint32_t* depth_out)
+{
+    if (!d || d->n_spheres == 0 || d->n_spheres > PT_REFERENCE_MAX_SPHERES || !d->sphere_pos_r) return 0;
+    pt::RefTreeBuilder b;
+    b.d = d;
+    for (uint32_t i = 0; i < rng_skip; ++i) (void)b.rng.f32();
+    b.order.resize(d->n_spheres);
+    for (uint32_t i = 0; i < d->n_spheres; ++i) b.order[i] = i;
+    b.boxes.reserve(2 * (size_t)d->n_spheres); b.links.reserve(6 * (size_t)d->n_spheres);
+    b.build(0, d->n_spheres, 0);
+    const uint32_t nn = (uint32_t)b.boxes.size();
+    if (depth_out) *depth_out = b.depth;
+    if (nn <= cap_nodes)
+    {
+        if (boxes6) memcpy(boxes6, b.boxes.data(), (size_t)nn * sizeof(pt::RefBox));
+        if (links3) memcpy(links3, b.links.data(), (size_t)nn * 3 * sizeof(int32_t));
+    }
+    if (order) memcpy(order, b.order.data(), (size_t)d->n_spheres * sizeof(uint32_t));
+    return nn;
 }
 
 int pt_scene_get_desc(const pt_scene* s, pt_scene_desc* out)

@@ -4,6 +4,7 @@ corrected as MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE/WRITE_SIZE are KB;
 of a wide coalesced read (x2); WRITE_SIZE is exact for 16-B-per-lane stores (our only stores)."""
 import csv, glob, json, os, sys
 d, key = sys.argv[1], sys.argv[2]
+run = sys.argv[3] if len(sys.argv) > 3 else os.path.basename(os.path.normpath(d))
 vals = {}
 for f in glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -11,7 +12,7 @@ for f in glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), rec
             vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]); write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"])
 out = {key: {"hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
-             "correction": "2*FETCH_SIZE + WRITE_SIZE, KB->B (MI355X_MICROARCH.md, HBM)"}}
+             "correction": "2*FETCH_SIZE + WRITE_SIZE, KB->B (MI355X_MICROARCH.md, HBM)", "run": run}}
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
 old = json.load(open(path)) if os.path.exists(path) else {}
 old.update(out)

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --cpu-spp 0 $*"
+BENCH="python3 $ROOT/bench.py --cpu-spp 0 --no-brute $*"
 echo "== kernel trace + stats" 
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
 i=0
@@ -24,4 +24,7 @@ for PMC in \
   echo "== pmc pass $i: $PMC"
   timeout -s KILL 300 rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- $BENCH > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -5 $OUT/pmc$i.log; }
 done
+# HBM bytes per launch of this very run -> profiles/traffic.json (bench.py quotes it with the run's tag)
+python3 $ROOT/tools/make_traffic.py $OUT ${PT_TRAFFIC_KEY:-scene1_1920x1080_spp512_d50} $TAG || echo "traffic.json not refreshed"
+mkdir -p $ROOT/gpurun_out/profiles_new && cp $ROOT/profiles/traffic.json $ROOT/gpurun_out/profiles_new/traffic.json
 echo done

@@ -164,6 +164,23 @@ template <class R> PT_DEV V3 random_point_in_unit_sphere(R& r)               // 
     return p;
 }
 template <class R> PT_DEV V3 random_unit_vector(R& r) { return normalize(random_point_in_unit_sphere(r)); } // utils.h:102-108
+// The same loop, left after `maxAttempts` rejected points (*found = false): the render loop lets such a lane try again
+// in the wave's next trip instead of keeping the whole wave in the loop (a wave of ~45 scattering lanes needs ~5.7
+// attempts for a mean of 1.9 per lane).  The draws are the uninterrupted loop's: the caller resumes at the same
+// position of the same stream.  maxAttempts = 0: never left early.
+template <class R> PT_DEV V3 random_point_in_unit_sphere_bounded(R& r, uint32_t maxAttempts, bool* found)
+{
+    V3 p = v3(0, 0, 0);
+    *found = true;
+    for (uint32_t attempt = 1;; ++attempt)
+    {
+        float z = rand_pm1(r), y = rand_pm1(r), x = rand_pm1(r);
+        p = v3(x, y, z);
+        if (norm_squared(p) <= kOnePlusUlp) break;                       // == (norm(p) <= 1.0f), see above
+        if (attempt == maxAttempts) { *found = false; break; }
+    }
+    return p;
+}
 template <class R> PT_DEV V3 random_point_in_unit_circle(R& r)               // utils.h:124-138
 {
     V3 p;
@@ -476,7 +493,7 @@ PT_DEV uint32_t pt_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readf
 // registers are short.  Parking it in LDS instead was tried: three more stack entries per lane cost the seventh
 // workgroup of a CU.)
 struct TravState { uint32_t cur; float best; int32_t bestSlot; uint32_t pk; };
-PT_DEV int32_t trav_plane(uint32_t pk) { return (int32_t)(pk >> 8) - 1; }
+PT_DEV int32_t trav_plane(uint32_t pk) { return (int32_t)((pk >> 8) & 0xFFu) - 1; } // (<= 64 planes; the bits above are the render loop's flags)
 PT_DEV void trav_begin(const BvhView& b, float tLimit, int32_t planeIdx, bool live, const QueryCtx& q, TravState& ts)
 {
     ts.best = tLimit;                  // a plane hit found earlier wins ties against spheres (main.cpp:204)
@@ -920,7 +937,11 @@ PT_DEV double reflectance(double cosine, double refractRatio)
 }
 
 // Second half of cast_ray (main.cpp:219-298).  Returns false when the path ends at this hit.
-template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray* out, uint32_t* event)
+// maxAttempts > 0: the unit-sphere rejection loop gives up after that many points and the event is EV_PENDING (nothing
+// but the RNG has changed; the caller calls again for the same hit and the loop goes on where it stopped).  Four attempts
+// are twelve draws = three Philox blocks exactly, so the stream stands on a block boundary, where every scatter starts anyway.
+enum : uint32_t { EV_PENDING = 5 };
+template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray* out, uint32_t* event, uint32_t maxAttempts = 0)
 {
     *event = EV_SCATTER;
     out->o = h.point;
@@ -933,7 +954,8 @@ template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray
     // both, so a wave pays max(attempts) once, not once per material branch.  Per lane the draws are unchanged.
     const bool roughMetal = h.m.type == MAT_METAL && h.m.roughness > 0.0f;
     V3 unitPoint = v3(0, 0, 0);
-    if (h.m.type == MAT_DIFFUSE || roughMetal) unitPoint = random_point_in_unit_sphere(rng);
+    bool found = true;
+    if (h.m.type == MAT_DIFFUSE || roughMetal) unitPoint = random_point_in_unit_sphere_bounded(rng, maxAttempts, &found);
     // Every material ends in `normalize(new direction)` (main.cpp:231, 251, 293): the branches below only pick the raw
     // direction, the normalisation -- an exact sqrt and three exact divides -- is issued once for the whole wave.
     V3 raw = v3(0, 0, 0);
@@ -980,6 +1002,7 @@ template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray
         return false;
     }
     out->d = normalize(raw);
+    if (!found) { *event = EV_PENDING; return true; }
     return lives;
 }
 
@@ -992,13 +1015,21 @@ PT_DEV V4 sky(const Ray& ray)                                            // main
 
 // One loop iteration of cast_ray.  Returns true while the path lives; when it ends, *terminal is the colour the
 // throughput must be multiplied with (sky, BLACK (0,0,0,1), or (0,0,0,0) for a NONE material).
+// pending != nullptr: bounded rejection loop (scatter's maxAttempts = kScatterAttempts); *pending = true means the hit
+// is not shaded yet -- ray, throughput and *terminal untouched, call again with the same hit.
+#ifndef PT_SCATTER_ATTEMPTS
+#define PT_SCATTER_ATTEMPTS 4
+#endif
+constexpr uint32_t kScatterAttempts = PT_SCATTER_ATTEMPTS;
 template <class R>
-PT_DEV bool shade_step(Ray& ray, const Hit& h, V4& throughput, R& rng, V4* terminal)
+PT_DEV bool shade_step(Ray& ray, const Hit& h, V4& throughput, R& rng, V4* terminal, bool* pending = nullptr)
 {
+    if (pending) *pending = false;
     if (h.t != kF32Max && h.t > 0)                                       // main.cpp:219
     {
         Ray next; uint32_t ev;
-        bool alive = scatter(ray, h, rng, &next, &ev);
+        bool alive = scatter(ray, h, rng, &next, &ev, pending ? kScatterAttempts : 0u);
+        if (ev == EV_PENDING) { *pending = true; return true; }
         if (!alive)
         {
             *terminal = (ev == EV_ABSORB) ? v4(0, 0, 0, 1) : v4(0, 0, 0, 0);

@@ -163,6 +163,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     // BVH kernels: a lane's sphere query may span several trips (bvh_run's early exit); ts.cur != kBvhDone marks a
     // lane whose query is under way.
     constexpr bool kBvh = RESUME && mode_is_bvh(MODE);
+    constexpr uint32_t kPendingShade = 0x40000000u; // in ts.pk: the finished query's hit has not got its scatter direction yet
     TravState ts; ts.cur = kBvhDone; ts.best = 0.0f; ts.bestSlot = -1; ts.pk = 0;
     for (uint32_t unit = waveId;;)
     {
@@ -239,7 +240,9 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
             bool ready = alive;
             if constexpr (kBvh)
             {
-                if (ts.cur == kBvhDone) // a new segment: planes first, then the tree from its root (a lane without a path parks on the sentinel)
+                // a new segment: planes first, then the tree from its root (a lane without a path parks on the sentinel);
+                // a lane whose hit still waits for its scatter direction (kPendingShade) keeps the finished query
+                if (ts.cur == kBvhDone && !(ts.pk & kPendingShade))
                 {
                     int32_t planeIdx = -1;
                     const float planeT = closest_plane(s, ray, &planeIdx);
@@ -254,10 +257,19 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
             PT_STAMP(ts2);
             if (ready)
             {
-                ++segs;
                 V4 terminal;
-                const bool goes_on = shade_step(ray, h, T, rng, &terminal);
+                bool pending = false;
+                const bool goes_on = shade_step(ray, h, T, rng, &terminal, kBvh && kScatterAttempts != 0u ? &pending : nullptr);
                 rng.park(); // the next scatter aligns to a fresh block anyway: drop the buffered words from the live state
+                if constexpr (kBvh)
+                {
+                    // The unit-sphere rejection loop is left after kScatterAttempts points: a lane still without one
+                    // keeps its hit (the traversal state is live anyway) and draws on in the wave's next trip.
+                    ts.pk = pending ? (ts.pk | kPendingShade) : (ts.pk & ~kPendingShade);
+                }
+                if (!pending)
+                {
+                ++segs;
                 rox = ray.o.x; roy = ray.o.y; roz = ray.o.z; rdx = ray.d.x; rdy = ray.d.y; rdz = ray.d.z;
                 bool ended = !goes_on;
                 if (goes_on && --depth == 0) { terminal = v4(0, 0, 0, 1); ended = true; } // main.cpp:175-176
@@ -276,6 +288,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
                     }
                     alive = false;
                 }
+                } // !pending
             }
 #ifdef PT_STAMPS
             PT_STAMP(ts3);

@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
+PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def flops_per_sample(sbar, n_spheres, n_planes, moving, box_tests_per_seg=None, leaf_tests_per_seg=None):
@@ -34,15 +35,15 @@ def flops_per_sample(sbar, n_spheres, n_planes, moving, box_tests_per_seg=None, 
     return 90.0 + sbar * (14.0 * n_planes + query) + (sbar - 1.0) * 75.0 + 8.0
 
 
-def cpu_baseline(scene_id, w, h, depth, spp, threads):
+def cpu_baseline(scene_id, w, h, depth, spp, threads, n_spheres=0):
     """The reference's own renderer (compiled into oracle/_ref) -- or, where that library is absent, our CPU
     restatement -- timed on the host cores on a bounded sample of the same workload (same scene, resolution and
     depth; fewer spp -- Msamples/s does not depend on spp)."""
     from oracle import pyoracle as po
     import pathtracer_amd as pt
     from tests._util import to_scene_arrays
-    sa = to_scene_arrays(pt.Scene.builtin(scene_id, w / h))
-    if po.Ref.available():
+    sa = to_scene_arrays(pt.Scene.builtin(scene_id, w / h, n_spheres))
+    if po.Ref.available() and sa.n_spheres <= 4192:   # the reference's World holds 4192 objects (render_world.h:85)
         R = po.Ref()
         hs = R.scene_from_arrays(sa)
         R.build_bvh(hs, 0)
@@ -81,6 +82,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", type=int, default=1)
+    ap.add_argument("--spheres", type=int, default=0, help="sphere count of scene 5 (C5: 1000000)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp-per-gpu", type=int, default=512)
@@ -115,7 +117,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     w, h, S, depth = args.width, args.height, args.spp_per_gpu, args.depth
-    scene = pt.Scene.builtin(args.scene, w / h)
+    scene = pt.Scene.builtin(args.scene, w / h, args.spheres)
     r = pt.Renderer(local_rank)
     r.upload(scene)
     accum = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
@@ -170,8 +172,8 @@ def main():
         moving = scene.vel is not None
         kernel_name = {0: "k_render<brute force, scene in LDS>", 1: "k_render<BVH in HBM>", 2: "k_render<strict search>", 3: "k_render<BVH in LDS>"}[st["kernel"]]
         is_bvh = st["kernel"] in (1, 3)
-        # an inner-node visit tests both child boxes (2 x 32 FLOP); leaf tests are per sphere
-        f_sample = flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving, 2.0 * nvis / segs, stest / segs) if is_bvh else \
+        # an inner-node visit tests every child box it holds (2 or 4 x 32 FLOP); leaf tests are per sphere
+        f_sample = flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving, float(st["node_width"] or 2) * nvis / segs, stest / segs) if is_bvh else \
             flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving)
         # roofline of the dominant kernel (k_render), per launch on one GPU
         achieved = (w * h * S) * f_sample / (kernel_ms * 1e-3) / 1e12
@@ -182,7 +184,7 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                t = json.load(open(tf)).get(f"scene{args.scene}_{w}x{h}_spp{S}_d{depth}", {})
+                t = json.load(open(tf)).get(f"scene{args.scene}{'_n' + str(args.spheres) if args.spheres else ''}_{w}x{h}_spp{S}_d{depth}", {})
                 traffic, traffic_run = t.get("hbm_bytes_per_launch"), t.get("run")
             except Exception:  # noqa: BLE001
                 traffic = None
@@ -201,28 +203,44 @@ def main():
                          "flop_per_sample": round(fb, 1), "achieved": round(tfl, 2), "frac": round(tfl / PEAK_FP32_TFLOPS, 4)}
             except pt.PtError:
                 brute = None   # the scene has no brute-force image in LDS
+        roof = {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic, "traffic_run": traffic_run,
+                "kernel": kernel_name, "flop_per_sample": round(f_sample, 1),
+                "box_tests_per_segment": round((st["node_width"] or 2) * nvis / segs, 2) if is_bvh else None,
+                "leaf_sphere_tests_per_segment": round(stest / segs, 2) if is_bvh else None,
+                "brute_force_kernel": brute,
+                "note": "FP32 vector (VALU) roofline, not MFMA (BASELINE.json north_star). Algorithmic FLOPs per SURVEY.md 8(d): "
+                        "for the BVH kernels the sphere term is 32/box test + 25|31/leaf test from device counters, so frac is the "
+                        "share of peak spent on algorithmically necessary FP32 work; brute_force_kernel is the measured figure of "
+                        "the brute-force formulation 8(d) prices (its own FLOPs over its own time)"}
+        if st["kernel"] == 1 and scene.n_spheres >= 32768:
+            # big trees in HBM (C5): SURVEY.md 8(d) prices them by bytes -- per segment node bytes x nodes visited + 32 B
+            # (sphere + material record) x leaf spheres tested, per pixel one 16-byte sum -- against the HBM peak
+            nb = float(st["node_bytes"])
+            bytes_launch = segs / world * (nb * nvis / segs + 32.0 * stest / segs) + 16.0 * w * h
+            gbs = bytes_launch / (kernel_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "traffic": traffic, "traffic_run": traffic_run, "kernel": kernel_name + f" ({st['node_width']}-wide nodes of {st['node_bytes']} B)",
+                    "algorithmic_bytes_per_launch": int(bytes_launch), "node_visits_per_segment": round(nvis / segs, 2),
+                    "leaf_sphere_tests_per_segment": round(stest / segs, 2),
+                    "valu": {"achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "flop_per_sample": round(f_sample, 1)},
+                    "note": "SURVEY.md 8(d): C5 is priced by algorithmic bytes (node bytes x visits + 32 B x leaf tests per segment + 16 B per pixel) against the "
+                            "8 TB/s HBM peak; `traffic` is what the HBM counters saw for the same launch (the tree is served by the L2 and the Infinity Cache: "
+                            "the kernel is bound by VALU issue at ~40 % lane activity, see profiles/README.md)"}
+        name = "book-1 scene 1080p" if (args.scene, w, h) == (1, 1920, 1080) else f"scene {args.scene} {w}x{h}"
         out = {
-            "metric": "Msamples/s (whole node) book-1 scene 1080p", "value": round(value, 2), "unit": "Msamples/s",
+            "metric": f"Msamples/s (whole node) {name}", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"init_test_scene_{args.scene} (book-1 final, {scene.n_spheres} spheres + {scene.n_planes} plane) "
+            "config": {"workload": f"{'init_test_scene_' + str(args.scene) if args.scene <= 3 else 'build-defined scene ' + str(args.scene)} ({'book-1 final, ' if args.scene == 1 else ''}{scene.n_spheres} spheres + {scene.n_planes} plane) "
                                    f"{w}x{h}, depth {depth}, {S} spp per GPU = {S * world} spp total",
                        "global_samples_per_step": samples_per_step, "parallelism": f"spp-split x{world} + RCCL all-reduce(sum) of the f32 accumulation buffer",
                        "segments_per_sample": round(sbar, 4), "lane_utilisation": round(st["segments"] / (64.0 * max(1, st["wave_iterations"])), 4), "kernel_ms": round(kernel_ms, 3), "lib_kernel_ms_last": round(st["kernel_ms"], 3)},
-            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic, "traffic_run": traffic_run,
-                         "kernel": kernel_name, "flop_per_sample": round(f_sample, 1),
-                         "box_tests_per_segment": round(2.0 * nvis / segs, 2) if is_bvh else None,
-                         "leaf_sphere_tests_per_segment": round(stest / segs, 2) if is_bvh else None,
-                         "brute_force_kernel": brute,
-                         "note": "FP32 vector (VALU) roofline, not MFMA (BASELINE.json north_star). Algorithmic FLOPs per SURVEY.md 8(d): "
-                                 "for the BVH kernels the sphere term is 32/box test + 25|31/leaf test from device counters, so frac is the "
-                                 "share of peak spent on algorithmically necessary FP32 work; brute_force_kernel is the measured figure of "
-                                 "the brute-force formulation 8(d) prices (its own FLOPs over its own time)"},
+            "roofline": roof,
         }
         if world == 1 and args.cpu_spp > 0:
             threads, host = host_threads()
-            out["cpu_baseline"] = cpu_baseline(args.scene, w, h, depth, args.cpu_spp, threads)
+            out["cpu_baseline"] = cpu_baseline(args.scene, w, h, depth, args.cpu_spp, threads, args.spheres)
             out["cpu_baseline"]["host"] = host
             out["config"]["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         assert host_img is not None and host_img.shape == (h, w)

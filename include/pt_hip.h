@@ -78,7 +78,7 @@ typedef struct pt_params {
 
 /* How the closest-sphere query is answered (all give the same definition of the answer):
  *   default            : BVH traversal with the tree staged in LDS when it fits (book-1 scene: 18 KB), else from HBM
- *                        (from 32768 spheres up as 32-byte nodes on a 16-bit grid; leaf tests stay exact)
+ *                        (from 32768 spheres up as 4-wide 64-byte nodes on a 16-bit grid; leaf tests stay exact)
  *   PT_FLAG_BRUTE_FORCE: two-level brute force over the LDS-resident SoA scene in packed FP32 (the FP32-VALU-bound
  *                        formulation of BASELINE.json's north star; approximate search + exact re-evaluation)
  *   PT_FLAG_STRICT_SEARCH: brute force in reference arithmetic for every sphere (slow; parity tests)
@@ -117,7 +117,9 @@ typedef struct pt_stats {
     uint64_t phase_cycles[3]; /* diagnostic builds (-DPT_STAMPS) only: shader cycles in refill / closest-hit / shading; else 0 */
     double kernel_ms;       /* HIP-event time of the render kernel on its stream */
     uint32_t kernel;        /* 0 = LDS brute force (fast), 1 = BVH in HBM, 2 = LDS brute force (strict), 3 = BVH in LDS, 4 = reference tree + pairwise combine */
-    uint32_t node_bytes;    /* bytes per tree node the BVH kernels read: 64 (float boxes) or 32 (16-bit grid boxes); 0 without a tree */
+    uint32_t node_bytes;    /* bytes per tree node the BVH kernels read: 64 (float boxes, or four 16-bit grid boxes) or 32 (two 16-bit grid boxes); 0 without a tree */
+    uint32_t node_width;    /* child boxes per node: 2, or 4 (big trees in HBM); 0 without a tree */
+    uint32_t reserved;
 } pt_stats;
 
 /* ---- device / context -------------------------------------------------------------------------------- */

@@ -57,7 +57,7 @@ class Params(C.Structure):  # pt_params
 class Stats(C.Structure):  # pt_stats
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64), ("node_visits", C.c_uint64),
                 ("wave_iterations", C.c_uint64), ("phase_cycles", C.c_uint64 * 3),
-                ("kernel_ms", C.c_double), ("kernel", C.c_uint32), ("node_bytes", C.c_uint32)]
+                ("kernel_ms", C.c_double), ("kernel", C.c_uint32), ("node_bytes", C.c_uint32), ("node_width", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _lib = None
@@ -311,7 +311,7 @@ class Renderer:
     def stats(self):
         s = Stats()
         self._check(self.L.pt_hip_last_stats(self.h, C.byref(s)), "pt_hip_last_stats")
-        d = {k: getattr(s, k) for k, _ in Stats._fields_ if k != "phase_cycles"}
+        d = {k: getattr(s, k) for k, _ in Stats._fields_ if k not in ("phase_cycles", "reserved")}
         d["phase_cycles"] = list(s.phase_cycles)
         return d
 
@@ -419,7 +419,7 @@ class Node:
         st = self.L.pt_hip_last_stats(C.c_void_p(self.L.pt_node_ctx(self.h, gpu)), C.byref(s))
         if st != PT_OK:
             raise PtError(st, "pt_hip_last_stats")
-        return {k: getattr(s, k) for k, _ in Stats._fields_ if k != "phase_cycles"}
+        return {k: getattr(s, k) for k, _ in Stats._fields_ if k not in ("phase_cycles", "reserved")}
 
 
 def spp_slice(spp_begin, spp_end, n_parts, part):

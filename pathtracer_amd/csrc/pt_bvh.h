@@ -318,4 +318,166 @@ inline void quantise_nodes(const BvhData& in, NodeGrid* grid, std::vector<uint32
     }
 }
 
+// ---- 64-byte 4-wide nodes for big trees in HBM (MODE_BVH_Q4) ------------------------------------------------------------
+// What bounds the traversal of a 10^6-sphere tree is the number of DEPENDENT fetches per ray (56 node visits + 16 sphere
+// loads per segment with 2-wide nodes, each as slow as the slowest of a wave's 64 lanes).  A wide node holds up to FOUR
+// child boxes on the same 16-bit grid (12 bytes each) + four references = 64 bytes = one fetch for two levels of the
+// binary tree; and the bottom of the tree names SINGLE spheres, each with its own box in its parent, so a sphere is
+// fetched only when the ray's cone touches its box (the 2-wide leaves fetch up to four spheres one after the other).
+//   node = 16 dwords:  child k (0..3): dwords 3k .. 3k+2 = {lo.x | hi.x << 16, lo.y | hi.y << 16, lo.z | hi.z << 16}
+//                      dwords 12..15 = references: inner -> wide node index; leaf -> kLeafFlag | (count-1) << 28 | first;
+//                      kNoChild = empty slot (its box is never looked at)
+// Built by collapsing the binary SAH tree: a node's two children are replaced, largest surface first, by THEIR children
+// until four are held (inner children only; leaves stay whole).  With `single` every multi-sphere leaf then becomes a
+// wide node of its own whose children are its spheres (or is inlined into its parent when there is room).
+constexpr uint32_t kNoChild = 0xFFFFFFFFu;
+struct WideData { std::vector<uint32_t> nodes; uint32_t n_nodes = 0, depth = 0, root_ref = 0; };
+inline void widen_nodes(const BvhData& in, const pt_scene_desc* d, bool single, NodeGrid* grid, WideData* out)
+{
+    out->nodes.clear(); out->n_nodes = 0; out->depth = 0; out->root_ref = in.root_ref;
+    for (int k = 0; k < 3; ++k) { grid->org[k] = 0.0f; grid->step[k] = 1.0f; }
+    if (in.n_spheres == 0) return;
+    struct Child { Aabb box; uint32_t ref; };
+    // the padded, swept box of one sphere slot, as build_bvh forms it (same pad: the leaf test is the exact one)
+    float extent = 1.0f;
+    for (int k = 0; k < 3; ++k) if (fabsf(d->camera[k]) > extent) extent = fabsf(d->camera[k]);
+    for (uint32_t sl = 0; sl < in.n_spheres; ++sl)
+        for (int k = 0; k < 3; ++k)
+        {
+            float a = fabsf(in.sph[4 * (size_t)sl + k]) + sqrtf(in.sph[4 * (size_t)sl + 3]);
+            if (in.moving) a += fabsf(in.vel[4 * (size_t)sl + k]) * (fabsf(d->t0) > fabsf(d->t1) ? fabsf(d->t0) : fabsf(d->t1));
+            if (a > extent) extent = a;
+        }
+    const float extentPad = extent * 1.0e-6f;
+    auto slot_box = [&](uint32_t sl) {
+        Aabb bx;
+        const float* s = in.sph.data() + 4 * (size_t)sl;
+        const float r = sqrtf(s[3]) * (1.0f + 1e-6f); // (r2 -> r rounds: a hair more)
+        for (int k = 0; k < 3; ++k)
+        {
+            float a = s[k], b2 = s[k];
+            if (in.moving) { const float v = in.vel[4 * (size_t)sl + k]; a = s[k] + v * d->t0; b2 = s[k] + v * d->t1; }
+            const float pad = extentPad + 1e-5f * r;
+            bx.lo[k] = (a < b2 ? a : b2) - r - pad; bx.hi[k] = (a > b2 ? a : b2) + r + pad;
+        }
+        return bx;
+    };
+    auto bin_child = [&](uint32_t node, int side) {
+        const float* nd = in.nodes.data() + 16 * (size_t)node;
+        Child c;
+        for (int k = 0; k < 3; ++k) { c.box.lo[k] = nd[6 * side + k]; c.box.hi[k] = nd[6 * side + 3 + k]; }
+        c.ref = f2u(nd[12 + side]);
+        return c;
+    };
+    auto leaf_first = [](uint32_t ref) { return ref & 0x0FFFFFFFu; };
+    auto leaf_count = [](uint32_t ref) { return ((ref >> 28) & 7u) + 1u; };
+    auto single_ref = [](uint32_t slot) { return kLeafFlag | slot; };
+    struct Wide { Child c[4]; uint32_t n = 0; };
+    std::vector<Wide> wide;
+    // work list: (children to place, index of the wide node to fill, its level)
+    struct Job { std::vector<Child> kids; uint32_t self, level; };
+    std::vector<Job> todo;
+    auto new_node = [&]() { wide.push_back(Wide{}); return (uint32_t)wide.size() - 1; };
+    auto leaf_kids = [&](uint32_t ref) { std::vector<Child> k; for (uint32_t i = 0; i < leaf_count(ref); ++i) k.push_back(Child{slot_box(leaf_first(ref) + i), single_ref(leaf_first(ref) + i)}); return k; };
+    if (in.n_nodes == 0)
+    {
+        // the whole scene is one leaf of the binary tree
+        if (!single || leaf_count(in.root_ref) == 1) return; // root_ref stays the leaf reference
+        todo.push_back(Job{leaf_kids(in.root_ref), new_node(), 1});
+        out->root_ref = 0;
+    }
+    else
+    {
+        todo.push_back(Job{{bin_child(0, 0), bin_child(0, 1)}, new_node(), 1});
+        out->root_ref = 0;
+    }
+    while (!todo.empty())
+    {
+        Job job = std::move(todo.back()); todo.pop_back();
+        if (job.level > out->depth) out->depth = job.level;
+        std::vector<Child>& kids = job.kids;
+        // pull grandchildren up, largest box first, while there is room
+        for (;;)
+        {
+            if (kids.size() >= 4) break;
+            int pick = -1; float area = -1.0f;
+            for (size_t j = 0; j < kids.size(); ++j)
+                if (!(kids[j].ref & kLeafFlag) && aabb_area(kids[j].box) > area) { area = aabb_area(kids[j].box); pick = (int)j; }
+            if (pick < 0) break;
+            const uint32_t node = kids[(size_t)pick].ref;
+            kids[(size_t)pick] = bin_child(node, 0);
+            kids.push_back(bin_child(node, 1));
+        }
+        if (single) // leaves of several spheres: inline them where there is room (smallest first), else give them a node
+            for (;;)
+            {
+                int pick = -1; uint32_t cnt = 9;
+                for (size_t j = 0; j < kids.size(); ++j)
+                    if ((kids[j].ref & kLeafFlag) && leaf_count(kids[j].ref) > 1 && leaf_count(kids[j].ref) < cnt && kids.size() - 1 + leaf_count(kids[j].ref) <= 4)
+                    { cnt = leaf_count(kids[j].ref); pick = (int)j; }
+                if (pick < 0) break;
+                const std::vector<Child> sp = leaf_kids(kids[(size_t)pick].ref);
+                kids[(size_t)pick] = sp[0];
+                kids.insert(kids.end(), sp.begin() + 1, sp.end());
+            }
+        Wide w; w.n = (uint32_t)kids.size();
+        for (uint32_t j = 0; j < w.n; ++j)
+        {
+            w.c[j] = kids[j];
+            if (!(kids[j].ref & kLeafFlag))                       // an inner node of the binary tree: a wide node of its own
+            {
+                const uint32_t self = new_node();
+                w.c[j].ref = self;
+                todo.push_back(Job{{bin_child(kids[j].ref, 0), bin_child(kids[j].ref, 1)}, self, job.level + 1});
+            }
+            else if (single && leaf_count(kids[j].ref) > 1)       // a leaf that did not fit: its spheres one level down
+            {
+                const uint32_t self = new_node();
+                w.c[j].ref = self;
+                todo.push_back(Job{leaf_kids(kids[j].ref), self, job.level + 1});
+            }
+        }
+        wide[job.self] = w;
+    }
+    out->n_nodes = (uint32_t)wide.size();
+    // one grid over everything
+    double lo[3] = {3e38, 3e38, 3e38}, hi[3] = {-3e38, -3e38, -3e38};
+    for (const Wide& w : wide)
+        for (uint32_t j = 0; j < w.n; ++j)
+            for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], (double)w.c[j].box.lo[k]); hi[k] = std::max(hi[k], (double)w.c[j].box.hi[k]); }
+    for (int k = 0; k < 3; ++k)
+    {
+        grid->org[k] = (float)lo[k];
+        if ((double)grid->org[k] > lo[k]) grid->org[k] = nextafterf(grid->org[k], -INFINITY);
+        double st = (hi[k] - (double)grid->org[k]) / 65535.0 * (1.0 + 1e-6);
+        if (!(st > 1e-30)) st = 1e-30;
+        grid->step[k] = (float)st;
+        if ((double)grid->step[k] < st) grid->step[k] = nextafterf(grid->step[k], INFINITY);
+    }
+    auto cell = [&](float v, int k, bool up) -> uint32_t {
+        const double org = grid->org[k], st = grid->step[k];
+        double g = up ? ceil(((double)v - org) / st) : floor(((double)v - org) / st);
+        if (g < 0) g = 0;
+        if (g > 65535) g = 65535;
+        if (up) { while (g < 65535 && org + g * st < (double)v) g += 1; }
+        else { while (g > 0 && org + g * st > (double)v) g -= 1; }
+        return (uint32_t)g;
+    };
+    out->nodes.assign(16 * (size_t)wide.size(), 0u);
+    for (size_t i = 0; i < wide.size(); ++i)
+    {
+        uint32_t* q = out->nodes.data() + 16 * i;
+        for (uint32_t j = 0; j < 4; ++j)
+        {
+            if (j < wide[i].n)
+            {
+                for (int k = 0; k < 3; ++k) q[3 * j + k] = cell(wide[i].c[j].box.lo[k], k, false) | cell(wide[i].c[j].box.hi[k], k, true) << 16;
+                q[12 + j] = wide[i].c[j].ref;
+            }
+            else
+                q[12 + j] = kNoChild;
+        }
+    }
+}
+
 } // namespace pth

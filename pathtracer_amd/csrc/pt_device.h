@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -441,37 +442,63 @@ PT_DEV bool box_hit(float lox, float loy, float loz, float hix, float hiy, float
 // brute-force search in that arithmetic -- the definition of the query -- finds them; the cone makes the tree visit them.
 constexpr float kConeEps = 1.0e-3f;
 PT_DEV bool cone_flat(float d) { return !(fabsf(d) > kConeEps * 1.001f); } // the cone outgrows this axis
-// lo planes go with (r2, n2), hi planes with (r1, n1); the coordinates are floats (64-byte nodes) or grid cells (32-byte
-// nodes, whose grid is folded into the pairs).  A flat axis needs no branch here: its hi-plane pair is (0, +big) (set up
-// once per ray in bvh_run), which makes that plane's value +big -- the axis then bounds t from below by its lo plane
-// alone and not from above: a superset of the cone/box overlap (the hi plane's lower bound is dropped), so conservative.
+// lo planes go with (r2, n2), hi planes with (r1, n1); the coordinates are floats (64-byte nodes) or grid cells (grid
+// nodes, whose grid is folded into the pairs).
+// A flat axis (|d| <= eps: d - eps < 0 < d + eps) bounds t from below with BOTH planes and not at all from above:
+//   FLAT_EXACT (trees in HBM): a side branch swaps the roles -- near = max of the two, far = +inf (~1e-3 of rays per axis).
+//     It matters there: a ray that runs parallel to a slab of 10^6 spheres, outside of it, is kept out of every box by
+//     that second bound; without it such a ray visits everything along its way, and a handful of those rays is the
+//     launch's tail (measured: C5 29 -> 146 ms).
+//   else (tree in LDS, a few hundred nodes): no branch; the hi-plane pair of a flat axis is (0, +big) (set up once per
+//     ray), i.e. that plane's value is +big -- its lower bound is dropped, a superset of the cone/box overlap.
+template <bool FLAT_EXACT>
 PT_DEV bool cone_planes(float lox, float hix, float loy, float hiy, float loz, float hiz, float r1x, float r1y, float r1z, float n1x, float n1y, float n1z,
-                        float r2x, float r2y, float r2z, float n2x, float n2y, float n2z, float best, float* tnear)
+                        float r2x, float r2y, float r2z, float n2x, float n2y, float n2z, bool anyFlat, V3 d, float best, float* tnear)
 {
 #pragma clang fp contract(fast)
     const float a0 = lox * r2x + n2x, a1 = hix * r1x + n1x;
     const float b0 = loy * r2y + n2y, b1 = hiy * r1y + n1y;
     const float c0 = loz * r2z + n2z, c1 = hiz * r1z + n1z;
-    const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
-    const float tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+    float nx = fminf(a0, a1), ny = fminf(b0, b1), nz = fminf(c0, c1);
+    float fx = fmaxf(a0, a1), fy = fmaxf(b0, b1), fz = fmaxf(c0, c1);
+    if (FLAT_EXACT && anyFlat)
+    {
+        if (cone_flat(d.x)) { nx = fx; fx = kF32Max; }
+        if (cone_flat(d.y)) { ny = fy; fy = kF32Max; }
+        if (cone_flat(d.z)) { nz = fz; fz = kF32Max; }
+    }
+    const float tn = fmaxf(fmaxf(nx, ny), nz);
+    const float tf = fminf(fminf(fx, fy), fz);
     *tnear = tn;
     return tf >= fmaxf(tn, 0.0f) && tn <= best;
 }
-PT_DEV bool box_hit_cone(float lox, float loy, float loz, float hix, float hiy, float hiz, float r1x, float r1y, float r1z, float n1x, float n1y, float n1z,
-                         float r2x, float r2y, float r2z, float n2x, float n2y, float n2z, float best, float* tnear)
+// the per-plane pairs of one axis (hi plane: t (d - eps) <= hi - o -> (r1, n1); lo plane: t (d + eps) >= lo - o -> (r2, n2));
+// on a flat axis the divisors are kept away from zero so that the reciprocals stay finite
+template <bool FLAT_EXACT>
+PT_DEV void cone_axis(float o, float d, float& r1, float& n1, float& r2, float& n2)
 {
-    return cone_planes(lox, hix, loy, hiy, loz, hiz, r1x, r1y, r1z, n1x, n1y, n1z, r2x, r2y, r2z, n2x, n2y, n2z, best, tnear);
+    const bool flat = cone_flat(d);
+    const float s2 = flat ? fmaxf(d + kConeEps, kConeEps * 1.0e-3f) : d + kConeEps;
+    r2 = __builtin_amdgcn_rcpf(s2); n2 = -o * r2;
+    if (FLAT_EXACT)
+    {
+        const float s1 = flat ? fminf(d - kConeEps, -kConeEps * 1.0e-3f) : d - kConeEps;
+        r1 = __builtin_amdgcn_rcpf(s1); n1 = -o * r1;
+    }
+    else
+    {
+        r1 = __builtin_amdgcn_rcpf(d - kConeEps); n1 = -o * r1;
+        if (flat) { r1 = 0.0f; n1 = 1.0e30f; }
+    }
 }
 
-// The reference-topology tree of PT_FLAG_REFERENCE_QUERY (host: pt_reference_bvh; 32 bytes per node in HBM):
-//   n0 = {box centre xyz, halfWidth}   n1 = {halfHeight, halfLength, bits(left), bits(right)}      (Rect3f, geometry.h:31-52)
-//   leaf: right = 0xFFFFFFFF and left = the sphere's SLOT in BvhView::sph / vel / mat.
 struct RefView { const float4* nodes; uint32_t root, n_nodes; };
 constexpr uint32_t kRefLeaf = 0xFFFFFFFFu;
 
 struct QueryCtx // per-lane scratch and counters of the sphere query
 {
     BvhView bvh; RefView ref; uint32_t* stack; uint32_t searched, nodeVisits, sphereTests, leafBatch;
+    uint32_t* ovf; uint32_t stackCap;            // MODE_BVH_Q4: levels >= stackCap of the traversal stack live in this per-lane (scratch) array
 #ifdef PT_STAMPS
     uint32_t innerIters, leafIters;              // wave-level trips through the two kinds of traversal step
     unsigned long long cycInner, cycLeaf;        // s_memtime spent in them
@@ -511,7 +538,7 @@ PT_DEV void trav_begin(const BvhView& b, float tLimit, int32_t planeIdx, bool li
 // stragglers keep their state (ts, LDS stack) and carry on in the next call, together with the rays the finished lanes
 // will have produced by then.  (Measured on book-1: 33 % of the inner steps and 44 % of the leaf steps of a
 // run-to-completion traversal are executed for fewer than 8 lanes.)
-template <bool MOVING, bool CONE, bool QN>
+template <bool MOVING, bool CONE, bool QN, bool FLAT_EXACT>
 PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, QueryCtx& q, TravState& ts, uint32_t minActive)
 {
     const uint32_t leafBatch = q.leafBatch;
@@ -538,20 +565,9 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
     float r2x = 0, r2y = 0, r2z = 0, n2x = 0, n2y = 0, n2z = 0;
     if (CONE)
     {
-        auto cone_axis = [](float o, float d, float& r1, float& n1, float& r2, float& n2)
-        {
-            // hi plane: t (d - eps) <= hi - o; lo plane: t (d + eps) >= lo - o.  On a flat axis (|d| <= eps) d - eps and
-            // d + eps straddle zero: both planes bound t from below, nothing bounds it from above.  There the hi-plane
-            // pair becomes (0, +big) -- its value is +big for every box, i.e. "no upper bound", and its lower bound is
-            // given up (conservative) -- and the lo-plane divisor is kept away from zero so the reciprocal stays finite.
-            const bool flat = cone_flat(d);
-            const float s2 = flat ? fmaxf(d + kConeEps, kConeEps * 1.0e-3f) : d + kConeEps;
-            r2 = __builtin_amdgcn_rcpf(s2); n2 = -o * r2;
-            r1 = __builtin_amdgcn_rcpf(d - kConeEps); n1 = -o * r1;
-            if (flat) { r1 = 0.0f; n1 = 1.0e30f; }
-        };
-        cone_axis(ray.o.x, ray.d.x, ix, nox, r2x, n2x); cone_axis(ray.o.y, ray.d.y, iy, noy, r2y, n2y); cone_axis(ray.o.z, ray.d.z, iz, noz, r2z, n2z);
+        cone_axis<FLAT_EXACT>(ray.o.x, ray.d.x, ix, nox, r2x, n2x); cone_axis<FLAT_EXACT>(ray.o.y, ray.d.y, iy, noy, r2y, n2y); cone_axis<FLAT_EXACT>(ray.o.z, ray.d.z, iz, noz, r2z, n2z);
     }
+    const bool anyFlat = CONE && FLAT_EXACT && (cone_flat(ray.d.x) || cone_flat(ray.d.y) || cone_flat(ray.d.z));
     if constexpr (QN) // fold the node grid into the per-plane pairs: (r, n) -> (step * r, org * r + n)
     {
         nox = b.gorg[0] * ix + nox; noy = b.gorg[1] * iy + noy; noz = b.gorg[2] * iz + noz;
@@ -589,10 +605,10 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
                     const float4 qa = b.nodes[2 * cur], qb = b.nodes[2 * cur + 1];
                     const uint32_t lx = __float_as_uint(qa.x), ly = __float_as_uint(qa.y), lz = __float_as_uint(qa.z);
                     const uint32_t rx = __float_as_uint(qa.w), ry = __float_as_uint(qb.x), rz = __float_as_uint(qb.y);
-                    hitL = cone_planes((float)(lx & 0xFFFFu), (float)(lx >> 16), (float)(ly & 0xFFFFu), (float)(ly >> 16), (float)(lz & 0xFFFFu), (float)(lz >> 16),
-                                       ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, cull, &nearL);
-                    hitR = cone_planes((float)(rx & 0xFFFFu), (float)(rx >> 16), (float)(ry & 0xFFFFu), (float)(ry >> 16), (float)(rz & 0xFFFFu), (float)(rz >> 16),
-                                       ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, cull, &nearR);
+                    hitL = cone_planes<FLAT_EXACT>((float)(lx & 0xFFFFu), (float)(lx >> 16), (float)(ly & 0xFFFFu), (float)(ly >> 16), (float)(lz & 0xFFFFu), (float)(lz >> 16),
+                                                   ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearL);
+                    hitR = cone_planes<FLAT_EXACT>((float)(rx & 0xFFFFu), (float)(rx >> 16), (float)(ry & 0xFFFFu), (float)(ry >> 16), (float)(rz & 0xFFFFu), (float)(rz >> 16),
+                                                   ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearR);
                     refL = __float_as_uint(qb.z); refR = __float_as_uint(qb.w);
                 }
                 else
@@ -601,9 +617,9 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
                     // the two references are half of the node's last 16 bytes: an 8-byte load (from HBM the compiler would fetch all 16)
                     const float2 n3 = *reinterpret_cast<const float2*>(b.nodes + 4 * cur + 3);
                     // left box {n0.xyz .. n0.w, n1.x, n1.y}, right box {n1.z, n1.w, n2.x .. n2.yzw}
-                    hitL = CONE ? box_hit_cone(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, cull, &nearL)
+                    hitL = CONE ? cone_planes<FLAT_EXACT>(n0.x, n0.w, n0.y, n1.x, n0.z, n1.y, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearL)
                                 : box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, cull, &nearL);
-                    hitR = CONE ? box_hit_cone(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, cull, &nearR)
+                    hitR = CONE ? cone_planes<FLAT_EXACT>(n1.z, n2.y, n1.w, n2.z, n2.x, n2.w, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearR)
                                 : box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, cull, &nearR);
                     refL = __float_as_uint(n3.x); refR = __float_as_uint(n3.y);
                 }
@@ -671,6 +687,147 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
     ts.cur = cur; ts.best = best; ts.bestSlot = bestSlot;
     ts.pk = (ts.pk & ~255u) | ((uint32_t)(sp - q.stack) >> 6);
 }
+// ---- the same traversal over 4-wide grid nodes (MODE_BVH_Q4; host: pt_bvh.h widen_nodes) ------------------------------
+// One 64-byte fetch decides up to four subtrees; the hit children are ordered near to far by one sorting network over
+// keys {bits of max(near, 0) with the child number in the two low bits} (positive floats order like unsigned integers,
+// a miss is all ones), the nearest is descended into, the others are pushed far first.  Up to three pushes per level
+// would make a worst-case stack of 3 x depth + 1 entries -- LDS that most rays never touch and that costs resident
+// waves -- so only the first `stackCap` levels live in LDS and deeper ones in a per-lane scratch array (q.ovf); the
+// branch around that path is wave-uniform and all but never taken.
+constexpr uint32_t kNoChild = 0xFFFFFFFFu;
+constexpr uint32_t kOvfEntries = 72;   // + the LDS levels: trees of up to (stackCap + 72 - 1) / 3 wide levels (host checks)
+PT_DEV void wide_push(const QueryCtx& q, uint32_t& level, uint32_t ref)
+{
+    ++level;
+    if (pt_ballot(level >= q.stackCap) == 0ull) q.stack[level * 64u] = ref;
+    else if (level < q.stackCap) q.stack[level * 64u] = ref;
+    else q.ovf[level - q.stackCap] = ref;
+}
+PT_DEV uint32_t wide_pop(const QueryCtx& q, uint32_t& level)
+{
+    uint32_t r;
+    if (pt_ballot(level >= q.stackCap) == 0ull) r = q.stack[level * 64u];
+    else if (level < q.stackCap) r = q.stack[level * 64u];
+    else r = q.ovf[level - q.stackCap];
+    if (r != kBvhDone) --level;           // (level 0 holds the sentinel and stays)
+    return r;
+}
+template <bool MOVING>
+PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live, QueryCtx& q, TravState& ts, uint32_t minActive)
+{
+    const uint32_t leafBatch = q.leafBatch;
+    float best = ts.best;
+    float cull = best * kCullSlack;      // (see bvh_run: boxes are culled with slack, the leaf test decides)
+    int32_t bestSlot = ts.bestSlot;
+    // cone test per plane: hi planes with (r1, n1), lo planes with (r2, n2), the node grid folded in (see bvh_run)
+    float r1x, r1y, r1z, n1x, n1y, n1z, r2x, r2y, r2z, n2x, n2y, n2z;
+    {
+        auto axis = [](float o, float d, float org, float step, float& r1, float& n1, float& r2, float& n2)
+        {
+            cone_axis<true>(o, d, r1, n1, r2, n2);
+            n1 = org * r1 + n1; n2 = org * r2 + n2; r1 *= step; r2 *= step;   // plane = org + cell * step
+        };
+        axis(ray.o.x, ray.d.x, b.gorg[0], b.gstep[0], r1x, n1x, r2x, n2x);
+        axis(ray.o.y, ray.d.y, b.gorg[1], b.gstep[1], r1y, n1y, r2y, n2y);
+        axis(ray.o.z, ray.d.z, b.gorg[2], b.gstep[2], r1z, n1z, r2z, n2z);
+    }
+    const bool anyFlat = cone_flat(ray.d.x) || cone_flat(ray.d.y) || cone_flat(ray.d.z);
+    const bool waveFlat = pt_ballot(anyFlat) != 0ull;   // ~1 wave in 6 holds such a ray at any time
+    uint32_t level = ts.pk & 255u;
+    uint32_t cur = ts.cur;
+    bool leave = false;
+    for (;;)
+    {
+        // ---- inner steps
+        for (;;)
+        {
+            const bool atInner = !(cur & kBvhLeafFlag);                  // (the sentinel carries the leaf flag)
+            const uint32_t nInner = (uint32_t)__popcll(pt_ballot(atInner));
+            const uint32_t nLeaf = (uint32_t)__popcll(pt_ballot(!atInner && cur != kBvhDone));
+            if (nInner == 0u || nLeaf >= leafBatch) break;
+            if (nInner + nLeaf < minActive && (uint32_t)__popcll(pt_ballot(live && cur == kBvhDone)) > nInner + nLeaf) { leave = true; break; }
+            q.nodeVisits += nInner;                                      // wave-level tally
+#ifdef PT_STAMPS
+            ++q.innerIters;
+#endif
+            if (atInner)
+            {
+                const float4 q0 = b.nodes[4 * cur], q1 = b.nodes[4 * cur + 1], q2 = b.nodes[4 * cur + 2], q3 = b.nodes[4 * cur + 3];
+                const uint32_t cx[4] = {__float_as_uint(q0.x), __float_as_uint(q0.w), __float_as_uint(q1.z), __float_as_uint(q2.y)};
+                const uint32_t cy[4] = {__float_as_uint(q0.y), __float_as_uint(q1.x), __float_as_uint(q1.w), __float_as_uint(q2.z)};
+                const uint32_t cz[4] = {__float_as_uint(q0.z), __float_as_uint(q1.y), __float_as_uint(q2.x), __float_as_uint(q2.w)};
+                const uint32_t ref[4] = {__float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w)};
+                uint32_t key[4];
+                // (the rare flat-axis fix-up is compiled into a copy of its own behind a WAVE-uniform branch: left to the
+                // compiler it becomes six selects per box for every ray)
+                auto test4 = [&](auto flatTag)
+                {
+                    constexpr bool kFlat = decltype(flatTag)::value;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k)
+                    {
+                        float tnear;
+                        const bool hit = cone_planes<kFlat>((float)(cx[k] & 0xFFFFu), (float)(cx[k] >> 16), (float)(cy[k] & 0xFFFFu), (float)(cy[k] >> 16),
+                                                            (float)(cz[k] & 0xFFFFu), (float)(cz[k] >> 16), r1x, r1y, r1z, n1x, n1y, n1z, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &tnear);
+                        key[k] = (hit && ref[k] != kNoChild) ? ((__float_as_uint(fmaxf(tnear, 0.0f)) & ~3u) | k) : 0xFFFFFFFFu;
+                    }
+                };
+                if (waveFlat) test4(std::true_type{}); else test4(std::false_type{});
+                const uint32_t a0 = min(key[0], key[1]), a1 = max(key[0], key[1]), c0 = min(key[2], key[3]), c1 = max(key[2], key[3]);
+                const uint32_t s0 = min(a0, c0), m0 = max(a0, c0), m1 = min(a1, c1), s3 = max(a1, c1);
+                const uint32_t s1 = min(m0, m1), s2 = max(m0, m1);
+                auto pick = [&](uint32_t k2) { const uint32_t lo = (k2 & 1u) ? ref[1] : ref[0], hi = (k2 & 1u) ? ref[3] : ref[2]; return (k2 & 2u) ? hi : lo; };
+                if (s0 == 0xFFFFFFFFu) cur = wide_pop(q, level);
+                else
+                {
+                    if (s3 != 0xFFFFFFFFu) wide_push(q, level, pick(s3));
+                    if (s2 != 0xFFFFFFFFu) wide_push(q, level, pick(s2));
+                    if (s1 != 0xFFFFFFFFu) wide_push(q, level, pick(s1));
+                    cur = pick(s0);
+                }
+            }
+        }
+        if (leave) break;
+        {
+            const unsigned long long act = pt_ballot(cur != kBvhDone);
+            if (act == 0ull) break;
+            if ((uint32_t)__popcll(act) < minActive && (uint32_t)__popcll(pt_ballot(live && cur == kBvhDone)) > (uint32_t)__popcll(act)) break;
+        }
+#ifdef PT_STAMPS
+        ++q.leafIters;
+#endif
+        // ---- leaf steps: every lane that waits at a leaf (as bvh_run)
+        const bool atLeaf = (cur & kBvhLeafFlag) && cur != kBvhDone;
+        const uint32_t first = cur & 0x0FFFFFFFu, count = atLeaf ? ((cur >> 28) & 7u) + 1u : 0u;
+        for (uint32_t k = 0;; ++k)
+        {
+            const unsigned long long todo = pt_ballot(k < count);
+            if (todo == 0ull) break;
+            q.sphereTests += (uint32_t)__popcll(todo);                   // wave-level tally
+            if (k < count)
+            {
+                const uint32_t slot = first + k;
+                const float4 sd = b.sph[slot];
+                V3 c = v3(sd.x, sd.y, sd.z);
+                if (MOVING) { const float4 vd = b.vel[slot]; c = add(c, mul(v3(vd.x, vd.y, vd.z), time)); } // main.cpp:66
+                if (!sphere_clearly_missed(ray, c, sd.w))
+                {
+                    const float t = intersect_sphere_exact(ray, c, sd.w);
+                    if (t > kMinT && t <= best)
+                    {
+                        bool take = t < best;
+                        if (!take && bestSlot >= 0)
+                            take = __float_as_uint(b.mat[2 * slot].w) < __float_as_uint(b.mat[2 * (uint32_t)bestSlot].w);
+                        if (take) { best = t; cull = t * kCullSlack; bestSlot = (int32_t)slot; }
+                    }
+                }
+            }
+        }
+        if (atLeaf) cur = wide_pop(q, level);
+    }
+    ts.cur = cur; ts.best = best; ts.bestSlot = bestSlot;
+    ts.pk = (ts.pk & ~255u) | level;
+}
 // The winner's centre, as the leaf test saw it.
 template <bool MOVING> PT_DEV V3 trav_centre(const BvhView& b, int32_t slot, float time)
 {
@@ -687,9 +844,9 @@ template <bool MOVING> PT_DEV V3 trav_centre(const BvhView& b, int32_t slot, flo
 struct Hit { float t; int32_t prim; V3 point, normal; Material m; };
 
 // How the sphere query is answered.
-enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2, MODE_BVH_LDS = 3, MODE_BVH_Q = 4, MODE_REF = 5 };
-constexpr bool mode_is_bvh(int m) { return m == MODE_BVH || m == MODE_BVH_LDS || m == MODE_BVH_Q; }
-constexpr bool mode_in_hbm(int m) { return m == MODE_BVH || m == MODE_BVH_Q; } // BVH / BVH_Q: tree read from HBM; BVH_LDS: tree staged in LDS
+enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2, MODE_BVH_LDS = 3, MODE_BVH_Q = 4, MODE_REF = 5, MODE_BVH_Q4 = 6 };
+constexpr bool mode_is_bvh(int m) { return m == MODE_BVH || m == MODE_BVH_LDS || m == MODE_BVH_Q || m == MODE_BVH_Q4; }
+constexpr bool mode_in_hbm(int m) { return m == MODE_BVH || m == MODE_BVH_Q || m == MODE_BVH_Q4; } // tree read from HBM; BVH_LDS: tree staged in LDS
 // Which traversals test boxes against a cone around the ray (box_hit_cone): all of them.  The cone is what makes the
 // tree agree with the brute-force definition of the query wherever the reference's sphere formula reports phantom hits
 // (far from the ray origin: big scenes, and rays that come back from a distant point of an infinite plane).
@@ -698,6 +855,15 @@ constexpr bool mode_uses_cone(int m) { return mode_in_hbm(m); }
 #else
 constexpr bool mode_uses_cone(int m) { return mode_is_bvh(m); }
 #endif
+
+// Which traversal answers MODE.
+template <bool MOVING, int MODE>
+PT_DEV void run_traversal(const BvhView& b, const Ray& ray, float time, bool live, QueryCtx& q, TravState& ts, uint32_t minActive)
+{
+    if constexpr (MODE == MODE_BVH_Q4) bvh_run_wide<MOVING>(b, ray, time, live, q, ts, minActive);
+    else bvh_run<MOVING, mode_uses_cone(MODE), MODE == MODE_BVH_Q, mode_in_hbm(MODE)>(b, ray, time, live, q, ts, minActive);
+}
+
 
 // ------------------------------------------------------------------ the reference's own query (PT_FLAG_REFERENCE_QUERY)
 // hit_test(Ray, Rect3f) (geometry.cpp:83-115) in the reference's arithmetic: here the box test decides the RESULT (a
@@ -856,7 +1022,7 @@ template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, cons
     {
         TravState ts;
         trav_begin(q.bvh, planeT, planeIdx, live, q, ts);
-        bvh_run<MOVING, mode_uses_cone(MODE), MODE == MODE_BVH_Q>(q.bvh, ray, time, live, q, ts, 0u);
+        run_traversal<MOVING, MODE>(q.bvh, ray, time, live, q, ts, 0u);
         return make_hit_bvh<MOVING>(s, ray, time, q, ts);
     }
     if (MODE == MODE_REF)

@@ -58,6 +58,7 @@ template <int MODE> __device__ __forceinline__ QueryCtx make_query(const SceneAr
         if (a.bvh_off[3] != 0xFFFFFFFFu) q.bvh.mat = smem + a.bvh_off[3]; // else: materials stay in HBM (touched once per hit)
     }
     q.ref = a.ref;
+    q.ovf = nullptr; q.stackCap = a.stack_entries;
     q.stack = stackBase; q.searched = 0; q.nodeVisits = 0; q.sphereTests = 0; q.leafBatch = a.leaf_batch;
 #ifdef PT_STAMPS
     q.innerIters = 0; q.leafIters = 0; q.cycInner = 0; q.cycLeaf = 0;
@@ -130,6 +131,8 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     float* acc = reinterpret_cast<float*>(smem + a.sc.blob_f4) + wave * 256u; // [64 pixels][rgba] of this wave's tile
     uint32_t* stack = reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4 + nwaves * 64u) + wave * (a.sc.stack_entries * 64u) + lane;
     QueryCtx qc = make_query<MODE>(a.sc, smem, stack);
+    uint32_t ovfStack[MODE == MODE_BVH_Q4 ? kOvfEntries : 1]; // levels of the traversal stack beyond its LDS part (bvh_run_wide)
+    qc.ovf = ovfStack;
     __syncthreads();
     const SceneView s = make_view(smem, a.sc);
     PhiloxRng rng; rng.init(a.seed, 0, 0);
@@ -248,7 +251,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
                     const float planeT = closest_plane(s, ray, &planeIdx);
                     trav_begin(qc.bvh, planeT, planeIdx, alive, qc, ts);
                 }
-                bvh_run<MOVING, mode_uses_cone(MODE), MODE == MODE_BVH_Q>(qc.bvh, ray, time, alive, qc, ts, a.sc.exit_lanes);
+                run_traversal<MOVING, MODE>(qc.bvh, ray, time, alive, qc, ts, a.sc.exit_lanes);
                 ready = alive && ts.cur == kBvhDone;
                 if (ready) h = make_hit_bvh<MOVING>(s, ray, time, qc, ts);
             }
@@ -404,6 +407,7 @@ template <bool MOVING, bool CARRY> RenderKernel render_kernel_mc(int mode, bool 
     if (mode == MODE_BVH_LDS) return render_kernel_for<MOVING, MODE_BVH_LDS, CARRY>(resume);
     if (mode == MODE_BVH) return render_kernel_for<MOVING, MODE_BVH, CARRY>(resume);
     if (mode == MODE_BVH_Q) return render_kernel_for<MOVING, MODE_BVH_Q, CARRY>(resume);
+    if (mode == MODE_BVH_Q4) return render_kernel_for<MOVING, MODE_BVH_Q4, CARRY>(resume);
     if (mode == MODE_LDS_STRICT) return render_kernel_for<MOVING, MODE_LDS_STRICT, CARRY>(resume);
     if (mode == MODE_REF) return render_kernel_for<MOVING, MODE_REF, CARRY>(resume);
     return render_kernel_for<MOVING, MODE_LDS_FAST, CARRY>(resume);
@@ -421,6 +425,7 @@ template <bool MOVING, int MODE> __global__ void __launch_bounds__(256) k_probe_
     extern __shared__ float4 smem[];
     stage_scene(smem, a.sc);
     QueryCtx qc = make_query<MODE>(a.sc, smem, reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4) + (threadIdx.x >> 6) * (a.sc.stack_entries * 64u) + (threadIdx.x & 63u));
+    uint32_t ovfStack[MODE == MODE_BVH_Q4 ? kOvfEntries : 1]; qc.ovf = ovfStack;
     __syncthreads();
     const SceneView s = make_view(smem, a.sc);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -483,6 +488,7 @@ template <bool MOVING, int MODE> __global__ void __launch_bounds__(256) k_probe_
     extern __shared__ float4 smem[];
     stage_scene(smem, a.sc);
     QueryCtx qc = make_query<MODE>(a.sc, smem, reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4) + (threadIdx.x >> 6) * (a.sc.stack_entries * 64u) + (threadIdx.x & 63u));
+    uint32_t ovfStack[MODE == MODE_BVH_Q4 ? kOvfEntries : 1]; qc.ovf = ovfStack;
     __syncthreads();
     const SceneView s = make_view(smem, a.sc);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -501,6 +507,7 @@ template <bool MOVING, int MODE> __global__ void __launch_bounds__(256) k_probe_
     extern __shared__ float4 smem[];
     stage_scene(smem, a.sc);
     QueryCtx qc = make_query<MODE>(a.sc, smem, reinterpret_cast<uint32_t*>(smem + a.sc.blob_f4) + (threadIdx.x >> 6) * (a.sc.stack_entries * 64u) + (threadIdx.x & 63u));
+    uint32_t ovfStack[MODE == MODE_BVH_Q4 ? kOvfEntries : 1]; qc.ovf = ovfStack;
     __syncthreads();
     const SceneView s = make_view(smem, a.sc);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -580,6 +587,7 @@ struct pt_ctx
     unsigned char* static_scratch = nullptr;      // this device's copy of g_static_scratch (pt_hip_render_device_static)
     uint32_t stat_slots = 0;
     bool bvh_q = false;   // the tree in HBM is stored as 32-byte grid nodes (MODE_BVH_Q)
+    bool bvh_wide = false; // ... as 64-byte 4-wide grid nodes (MODE_BVH_Q4)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int last_mode = MODE_LDS_FAST;
@@ -615,11 +623,16 @@ constexpr uint32_t kMinResidentWaves = 16; // per CU: below this the LDS-residen
 // BVH traversal: bvh_run's minActive for the tree in LDS and in HBM (book-1 1080p: 105.1 -> 102.2 ms with 8, flat
 // from 6 to 12; 10^6 spheres 4K: 431 -> 594 -> 669 -> 700 Msamples/s with 0, 8, 16, 24); a single-leaf tree (up to 4 spheres) has no stragglers and skips it.
 constexpr uint32_t kExitLanes = 8, kExitLanesHbm = 24, kResumeMinSpheres = 4;
-constexpr uint32_t kGridNodeMinSpheres = 32768; // from here on the tree in HBM uses 32-byte grid nodes
+constexpr uint32_t kGridNodeMinSpheres = 32768; // from here on the tree in HBM uses grid nodes (4-wide)
+constexpr uint32_t kWideStackLds = 24;          // 4-wide traversal: stack levels kept in LDS (deeper ones: per-lane scratch)
 // Lanes that must be out of work before the wave runs the refill code (render_body).  Scene in LDS: flat from 20 to 36 on
 // book-1, +2-4 % at 28-36 on the small scenes; tree in HBM (trips dear, refill cheap by comparison): 12.
 constexpr uint32_t kRefillMin = 28, kRefillMinHbm = 12;
 constexpr uint32_t kLeafBatch = 16; // BVH traversal: lanes gathered at leaves before the leaf code runs (pt_device.h, bvh_closest)
+// 4-wide nodes over single spheres (10^6 spheres 4K, 8 spp): a leaf step is one sphere test, so lanes wait for fewer
+// companions (leaf batch 1 / 4 / 8 / 16 / 32: 1106 / 1212 / 1242 / 1171 / 938 Msamples/s at exit 40) and the traversal
+// phase is left as soon as the finished lanes outnumber the others (exit 16 / 24 / 40-64: 1154 / 1187 / 1230-1245).
+constexpr uint32_t kLeafBatchWide = 8, kExitLanesWide = 48;
 
 uint32_t pick_stride(uint32_t ntiles)
 {
@@ -669,7 +682,7 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
     else
     {
         if (flags & PT_FLAG_FORCE_LDS) return PT_ERR_UNSUPPORTED;
-        *mode = ctx->bvh_q ? MODE_BVH_Q : MODE_BVH; *sc = &ctx->sc_bvh;
+        *mode = ctx->bvh_wide ? MODE_BVH_Q4 : ctx->bvh_q ? MODE_BVH_Q : MODE_BVH; *sc = &ctx->sc_bvh;
     }
     const size_t stack = mode_is_bvh(*mode) ? (size_t)(*sc)->stack_entries * 64 * 4 : 0;
     *lds = (size_t)(*sc)->blob_f4 * 16 + waves * ((acc ? kAccBytesPerWave : 0) + stack);
@@ -682,8 +695,8 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
     do {                                                                                                        \
         int st_ = PT_OK;                                                                                        \
         auto go_ = [&](auto kern) { st_ = set_lds(ctx, kern, lds); if (st_ == PT_OK) hipLaunchKernelGGL(kern, grid, block, lds, stream, args); }; \
-        if (moving) { if (mode == MODE_BVH_LDS) go_(KERNEL<true, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<true, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<true, MODE_BVH_Q>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<true, MODE_LDS_STRICT>); else if (mode == MODE_REF) go_(KERNEL<true, MODE_REF>); else go_(KERNEL<true, MODE_LDS_FAST>); } \
-        else        { if (mode == MODE_BVH_LDS) go_(KERNEL<false, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<false, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<false, MODE_BVH_Q>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<false, MODE_LDS_STRICT>); else if (mode == MODE_REF) go_(KERNEL<false, MODE_REF>); else go_(KERNEL<false, MODE_LDS_FAST>); } \
+        if (moving) { if (mode == MODE_BVH_LDS) go_(KERNEL<true, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<true, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<true, MODE_BVH_Q>); else if (mode == MODE_BVH_Q4) go_(KERNEL<true, MODE_BVH_Q4>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<true, MODE_LDS_STRICT>); else if (mode == MODE_REF) go_(KERNEL<true, MODE_REF>); else go_(KERNEL<true, MODE_LDS_FAST>); } \
+        else        { if (mode == MODE_BVH_LDS) go_(KERNEL<false, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<false, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<false, MODE_BVH_Q>); else if (mode == MODE_BVH_Q4) go_(KERNEL<false, MODE_BVH_Q4>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<false, MODE_LDS_STRICT>); else if (mode == MODE_REF) go_(KERNEL<false, MODE_REF>); else go_(KERNEL<false, MODE_LDS_FAST>); } \
         if (st_ != PT_OK) return st_;                                                                           \
     } while (0)
 
@@ -851,10 +864,29 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         st = upload_f4(ctx, ctx->blob_planes.f4.data(), ctx->blob_planes.f4.size() * 16, &ctx->blob_planes_dev); if (st != PT_OK) return st;
         // Big trees are read from HBM as 32-byte grid nodes (half the loads per step: the L1 is what binds that kernel);
         // small ones, resident in L1/L2 and bound by instruction issue, keep the 64-byte float nodes.
-        ctx->bvh_q = bv.n_spheres >= kGridNodeMinSpheres;
-        if (const char* e = getenv("PT_GRID_NODES")) ctx->bvh_q = atoi(e) != 0 && bv.n_nodes != 0; // tests / tuning experiments
+        // ... and from kGridNodeMinSpheres up as 64-byte 4-wide grid nodes over single spheres (MODE_BVH_Q4): half the
+        // dependent fetches per ray.  PT_GRID_NODES (tests / tuning): 0 float nodes, 1 32-byte 2-wide, 2 4-wide over
+        // the binary tree's leaves, 3 4-wide over single spheres (the default for big trees).
+        int gridKind = bv.n_spheres >= kGridNodeMinSpheres ? 3 : 0;
+        if (const char* e = getenv("PT_GRID_NODES")) gridKind = atoi(e);
+        if (gridKind < 0 || gridKind > 3) gridKind = 0;
+        if (bv.n_spheres == 0) gridKind = 0;
+        ctx->bvh_q = gridKind == 1 && bv.n_nodes != 0;
+        ctx->bvh_wide = false;
         pth::NodeGrid grid{};
-        if (ctx->bvh_q)
+        pth::WideData wd;
+        if (gridKind >= 2)
+        {
+            pth::widen_nodes(bv, d, gridKind == 3, &grid, &wd);
+            // (a tree too deep for the stack's LDS + scratch levels keeps the 2-wide grid nodes)
+            if (wd.n_nodes != 0 && 3u * wd.depth + 1u <= kWideStackLds + kOvfEntries) ctx->bvh_wide = true;
+            else ctx->bvh_q = bv.n_nodes != 0;
+        }
+        if (ctx->bvh_wide)
+        {
+            st = upload_f4(ctx, wd.nodes.data(), wd.nodes.size() * 4, &ctx->nodes_dev); if (st != PT_OK) return st;
+        }
+        else if (ctx->bvh_q)
         {
             std::vector<uint32_t> qn;
             pth::quantise_nodes(bv, &grid, &qn);
@@ -868,15 +900,25 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         st = upload_f4(ctx, bv.vel.data(), bv.vel.size() * 4, &ctx->vel_dev); if (st != PT_OK) return st;
         st = upload_f4(ctx, bv.mat.data(), bv.mat.size() * 4, &ctx->mat_dev); if (st != PT_OK) return st;
         fill_scene_args(&ctx->sc_bvh, ctx->blob_planes, ctx->blob_planes_dev, d, d->n_planes);
-        ctx->sc_bvh.bvh = BvhView{ctx->nodes_dev, ctx->sph_dev, ctx->vel_dev, ctx->mat_dev, bv.root_ref, bv.n_spheres,
+        ctx->sc_bvh.bvh = BvhView{ctx->nodes_dev, ctx->sph_dev, ctx->vel_dev, ctx->mat_dev, ctx->bvh_wide ? wd.root_ref : bv.root_ref, bv.n_spheres,
                                   {grid.org[0], grid.org[1], grid.org[2]}, {grid.step[0], grid.step[1], grid.step[2]}};
         ctx->sc_bvh.stack_entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1; // the sentinel + at most one pushed sibling per inner node of a root-to-leaf path (bv.depth of them)
+        if (ctx->bvh_wide)
+        {
+            // up to three pushed siblings per level; the first kWideStackLds levels in LDS, the rest in scratch (pt_device.h)
+            uint32_t capLds = kWideStackLds;
+            if (const char* e = getenv("PT_WIDE_STACK")) { int v = atoi(e); if (v >= 2 && v <= 255) capLds = (uint32_t)v; } // tuning experiments only
+            const uint32_t need = 3u * wd.depth + 1u;
+            ctx->sc_bvh.stack_entries = need < capLds ? (need < 4 ? 4 : need) : capLds;
+            if (need > ctx->sc_bvh.stack_entries + kOvfEntries) { ctx->err = "wide BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
+        }
         ctx->sc_bvh.leaf_batch = kLeafBatch;
         int exitEnv = -1;
         if (const char* e = getenv("PT_EXIT_LANES")) { int v = atoi(e); if (v >= 0 && v <= 64) exitEnv = v; } // tuning experiments only
         const bool resumable = bv.n_spheres > kResumeMinSpheres;
 
-        ctx->sc_bvh.exit_lanes = !resumable ? 0u : exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanesHbm;
+        ctx->sc_bvh.exit_lanes = !resumable ? 0u : exitEnv >= 0 ? (uint32_t)exitEnv : ctx->bvh_wide ? kExitLanesWide : kExitLanesHbm;
+        if (ctx->bvh_wide) ctx->sc_bvh.leaf_batch = kLeafBatchWide;
         const uint32_t refillLds = ctx->sc_bvh.refill_min; // (fill_scene_args: the default, or PT_REFILL_MIN)
         if (!getenv("PT_REFILL_MIN")) ctx->sc_bvh.refill_min = kRefillMinHbm;
         if (const char* e = getenv("PT_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->sc_bvh.leaf_batch = (uint32_t)v; } // tuning experiments only
@@ -893,7 +935,7 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         for (uint32_t slot = 0; slot < bv.n_spheres; ++slot) ctx->slot_of_sphere[pth::f2u(bv.mat[8 * (size_t)slot + 3])] = slot;
         if (bv.depth + 1 > kBvhStack) { ctx->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
         // (3) the same tree staged in LDS behind the planes, when planes + tree + payload + 4 waves' stacks fit
-        const uint32_t entries = ctx->sc_bvh.stack_entries;
+        const uint32_t entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1; // (the binary tree's: sc_bvh may hold the 4-wide tree's figure)
         // Materials are read once per hit, the tree and the spheres at every step: only the latter are worth LDS, and
         // the smaller image lets more waves share a CU.
         const bool matInLds = getenv("PT_MAT_LDS") != nullptr; // tuning experiments only
@@ -1107,6 +1149,7 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
     ctx->last.samples = (uint64_t)p->width * p->height * a.nspp;
     ctx->last.kernel = mode_in_hbm(mode) ? 1u : mode == MODE_BVH_LDS ? 3u : mode == MODE_LDS_STRICT ? 2u : mode == MODE_REF ? 4u : 0u;
     ctx->last.node_bytes = mode == MODE_BVH_Q ? 32u : mode_is_bvh(mode) ? 64u : 0u;
+    ctx->last.node_width = mode == MODE_BVH_Q4 ? 4u : mode_is_bvh(mode) ? 2u : 0u;
     return PT_OK;
 }
 
@@ -1240,6 +1283,49 @@ int pt_bvh_selfcheck(const pt_scene_desc* d, uint64_t out8[8])
                 }
             }
         }
+    }
+    // the 4-wide grid nodes, both flavours (leaves of the binary tree / single spheres): every sphere under exactly one
+    // leaf reference and inside the decoded box of the child that leads to it, references in range
+    for (int single = 0; single < 2 && bv.n_spheres != 0; ++single)
+    {
+        pth::NodeGrid wg{}; pth::WideData wd;
+        pth::widen_nodes(bv, d, single != 0, &wg, &wd);
+        if (getenv("PT_VERBOSE")) fprintf(stderr, "pt_bvh_selfcheck: binary %u nodes depth %u; wide(%d) %u nodes depth %u\n", bv.n_nodes, bv.depth, single, wd.n_nodes, wd.depth);
+        uint64_t found = 0;
+        auto wide_leaf = [&](uint32_t ref, const float* lo, const float* hi) {
+            const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 7u) + 1u;
+            if ((uint64_t)first + count > bv.n_spheres || (single && count != 1 && wd.n_nodes != 0)) { ++out8[7]; return; }
+            for (uint32_t i = 0; i < count; ++i) { ++found; if (lo && !sphere_inside(first + i, lo, hi)) ++out8[5]; }
+        };
+        if (wd.n_nodes == 0) wide_leaf(wd.root_ref, nullptr, nullptr);
+        else
+        {
+            std::vector<uint32_t> stack{wd.root_ref};
+            std::vector<char> seen(wd.n_nodes, 0);
+            uint64_t visited = 0;
+            while (!stack.empty())
+            {
+                const uint32_t node = stack.back(); stack.pop_back();
+                if (node >= wd.n_nodes || seen[node]) { ++out8[7]; continue; }
+                seen[node] = 1; ++visited;
+                const uint32_t* q = wd.nodes.data() + 16 * (size_t)node;
+                for (int j = 0; j < 4; ++j)
+                {
+                    const uint32_t ref = q[12 + j];
+                    if (ref == pth::kNoChild) continue;
+                    float lo[3], hi[3];
+                    for (int k = 0; k < 3; ++k)
+                    {
+                        // what the device's arithmetic makes of the cell can differ from this by rounding; the builder's pad covers it
+                        lo[k] = (float)((double)wg.org[k] + (double)(q[3 * j + k] & 0xFFFFu) * (double)wg.step[k]);
+                        hi[k] = (float)((double)wg.org[k] + (double)(q[3 * j + k] >> 16) * (double)wg.step[k]);
+                    }
+                    if (ref & pth::kLeafFlag) wide_leaf(ref, lo, hi); else stack.push_back(ref);
+                }
+            }
+            if (visited != wd.n_nodes) ++out8[7];
+        }
+        if (found != bv.n_spheres) ++out8[7];
     }
     return (out8[4] == bv.n_spheres && out8[5] == 0 && out8[6] == 0 && out8[7] == 0) ? PT_OK : PT_ERR_INVALID;
 }

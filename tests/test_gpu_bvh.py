@@ -153,12 +153,17 @@ def test_large_scene_reproduces_the_reference_formulas_phantom_hits(renderer, or
         assert phantom or close, (int(i), int(prim[i]), float(t[i]), int(po_[i]), float(to[i]), bands)
 
 
+@pytest.mark.parametrize("kind,stack", [(1, 0), (2, 0), (3, 0), (3, 3)])
 @pytest.mark.parametrize("name", ["scene2_2400", "scene1_forced", "scene3_moving_forced", "random_moving_300_forced", "tiny_3_forced"])
-def test_grid_nodes_bit_exact(renderer, oracle, monkeypatch, name):
-    """The 32-byte grid nodes that big trees in HBM use (>= 32768 spheres by default; the 10^5-sphere test below runs on
-    them) forced onto small scenes: the boxes only decide which leaves are visited, so hits, per-sample radiance and
-    rendered frames stay the oracle's, to the bit."""
-    monkeypatch.setenv("PT_GRID_NODES", "1")
+def test_grid_nodes_bit_exact(renderer, oracle, monkeypatch, name, kind, stack):
+    """The grid-node formats of trees in HBM forced onto small scenes -- kind 1: 32-byte 2-wide nodes; 2: 64-byte 4-wide
+    nodes over the binary tree's leaves; 3: 4-wide over single spheres, what big trees (>= 32768 spheres: the 10^5- and
+    10^6-sphere tests) get by default; stack 3: only three levels of the 4-wide traversal's stack in LDS, so the
+    per-lane scratch levels are exercised.  The boxes only decide which leaves are visited, so hits, per-sample radiance
+    and rendered frames stay the oracle's, to the bit."""
+    monkeypatch.setenv("PT_GRID_NODES", str(kind))
+    if stack:
+        monkeypatch.setenv("PT_WIDE_STACK", str(stack))
     sa, flags = SCENES[name]
     flags |= pt.FLAG_FORCE_BVH
     renderer.upload(to_pt_scene(sa))
@@ -179,6 +184,8 @@ def test_grid_nodes_bit_exact(renderer, oracle, monkeypatch, name):
         st = renderer.stats()
         ref, seg = oracle.render_philox(h, 96, 54, 0, 12, 50, seed=19)
         assert st["kernel"] == 1 and st["segments"] == seg, name
+        if sa.n_spheres > 4:
+            assert (st["node_bytes"], st["node_width"]) == {1: (32, 2), 2: (64, 4), 3: (64, 4)}[kind], (name, kind, st)
         assert np.abs(img.astype(np.float64) - ref.astype(np.float64)).max() <= 2 * 12 * 2.0 ** -24 * max(1.0, float(np.abs(ref).max()))
     finally:
         oracle.scene_free(h)
@@ -186,7 +193,7 @@ def test_grid_nodes_bit_exact(renderer, oracle, monkeypatch, name):
 
 def test_c5_million_spheres_4k(renderer, oracle):
     """BASELINE.json config 5 at its full size: 10^6 random spheres + ground plane, 3840x2160, depth 50, through the
-    default path (flags = 0: tree in HBM, 32-byte grid nodes).  A few spp of the whole frame for the size-independent
+    default path (flags = 0: tree in HBM, 4-wide grid nodes over single spheres).  A few spp of the whole frame for the size-independent
     properties; bit-equality with the brute-force oracle (10^6 exact sphere tests per segment) on a strided subset of
     rays and of whole samples."""
     w, hgt, depth, spp = 3840, 2160, 50, 3
@@ -195,7 +202,7 @@ def test_c5_million_spheres_4k(renderer, oracle):
     renderer.upload(to_pt_scene(sa))
     img = renderer.render(w, hgt, 0, spp, depth, seed=12)
     st = renderer.stats()
-    assert st["kernel"] == 1 and st["node_bytes"] == 32                              # tree in HBM, grid nodes
+    assert st["kernel"] == 1 and (st["node_bytes"], st["node_width"]) == (64, 4)     # tree in HBM, 4-wide grid nodes
     assert st["samples"] == w * hgt * spp
     assert np.isfinite(img).all() and (img >= 0).all()
     assert np.allclose(img[..., 3], spp, rtol=1e-6)                                  # every sample landed exactly once

@@ -24,7 +24,7 @@ def test_library_exports_exactly_the_header(golden_dir):
     # every replaced reference interface is cited (file:line) next to its declaration
     assert len(re.findall(r"src/[a-z_]+\.(?:cpp|h):\d+", header)) >= 25
     # ctypes mirrors of the structs have the C sizes
-    assert C.sizeof(pt.Params) == 32 and C.sizeof(pt.Stats) == 80 and C.sizeof(pt.SceneDesc) == 152
+    assert C.sizeof(pt.Params) == 32 and C.sizeof(pt.Stats) == 88 and C.sizeof(pt.SceneDesc) == 152
 
 
 def test_status_codes_without_gpu():

@@ -624,7 +624,7 @@ constexpr uint32_t kMinResidentWaves = 16; // per CU: below this the LDS-residen
 // from 6 to 12; 10^6 spheres 4K: 431 -> 594 -> 669 -> 700 Msamples/s with 0, 8, 16, 24); a single-leaf tree (up to 4 spheres) has no stragglers and skips it.
 constexpr uint32_t kExitLanes = 8, kExitLanesHbm = 24, kResumeMinSpheres = 4;
 constexpr uint32_t kGridNodeMinSpheres = 32768; // from here on the tree in HBM uses grid nodes (4-wide)
-constexpr uint32_t kWideStackLds = 24;          // 4-wide traversal: stack levels kept in LDS (deeper ones: per-lane scratch)
+constexpr uint32_t kWideStackLds = 16;          // 4-wide traversal: stack levels kept in LDS, deeper ones in per-lane scratch (C5, 37 levels needed: 10-20 in LDS 1297-1303 Msamples/s, 24: 1233 -- fewer resident waves)
 // Lanes that must be out of work before the wave runs the refill code (render_body).  Scene in LDS: flat from 20 to 36 on
 // book-1, +2-4 % at 28-36 on the small scenes; tree in HBM (trips dear, refill cheap by comparison): 12.
 constexpr uint32_t kRefillMin = 28, kRefillMinHbm = 12;

@@ -220,7 +220,8 @@ int pt_bvh_selfcheck(const pt_scene_desc* scene, uint64_t out8[8]);
 
 /* Diagnostics (no reference counterpart): the raw device counter words of the last render, for the tuning tools under
  * tools/.  [0] segments [1] wave iterations [2..4] phase cycles [5] groups searched [6] node visits [7] sphere tests
- * [8] units handed out [9] wave-level inner-step trips [10] wave-level leaf-step trips [11..12] their cycles (stamps build). */
+ * [8] units handed out [9] wave-level inner-step trips [10] wave-level leaf-step trips [11..12] their cycles (stamps build)
+ * [13] paths that ended after their unit's tile was flushed (each adds its rgba to the image with four float atomics). */
 int pt_hip_debug_counters(pt_ctx* ctx, uint64_t out16[16]);
 
 /* Replaces: `clamp(pixelColour/SAMPLES_PER_PIXEL, 0, 1)` (src/main.cpp:358) and the per-pixel part of

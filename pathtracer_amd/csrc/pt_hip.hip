@@ -44,6 +44,7 @@ struct SceneArgs
     uint32_t refill_min;
     uint32_t exit_lanes;    // a trip's traversal phase is left once fewer lanes than this still traverse and one is ready to shade
     RefView ref;            // MODE_REF: the reference-topology tree (PT_FLAG_REFERENCE_QUERY)
+    uint32_t carry_max;     // CARRY kernels: a unit whose pool is empty is left once at most this many of its paths are still under way
 };
 
 // LDS carve-up behind the scene image: per wave, [64 pixels x rgba] accumulators (render kernel) and, in the BVH modes,
@@ -136,7 +137,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     __syncthreads();
     const SceneView s = make_view(smem, a.sc);
     PhiloxRng rng; rng.init(a.seed, 0, 0);
-    uint32_t segs = 0, iters = 0;
+    uint32_t segs = 0, iters = 0, ncarried = 0;
 #ifdef PT_STAMPS
     unsigned long long cyc_refill = 0, cyc_hit = 0, cyc_shade = 0;
 #define PT_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -223,7 +224,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
                 }
                 next += (uint32_t)__popcll(need);
             }
-            if (CARRY && haveUnit && next >= total)
+            if (CARRY && haveUnit && next >= total && (uint32_t)__popcll(pt_ballot(alive)) <= a.sc.carry_max)
             {
                 // The pool is empty: whoever is still under way is carried (its tile pixel becomes an index into the image).
                 if (alive && !(p & kCarried))
@@ -281,6 +282,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
                     const V4 c = hadamard(T, terminal);
                     if (p & kCarried)
                     {
+                        ncarried += (uint32_t)__popcll(pt_ballot(true)); // (wave-level tally: a scalar add)
                         float* dst = image + 4u * (size_t)(p & ~kCarried);
                         unsafeAtomicAdd(dst, c.x); unsafeAtomicAdd(dst + 1, c.y); unsafeAtomicAdd(dst + 2, c.z); unsafeAtomicAdd(dst + 3, c.w);
                     }
@@ -339,7 +341,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     if (lane == 0)
     {
         unsigned long long* slot = a.stats + kStatWords * (1u + waveId);
-        slot[0] = segs; slot[1] = iters; slot[5] = qc.searched;
+        slot[0] = segs; slot[1] = iters; slot[5] = qc.searched; slot[13] = ncarried;
         slot[6] = (mode_is_bvh(MODE) || MODE == MODE_REF) ? qc.nodeVisits : 0u; // both tallies are wave-level already
         slot[7] = (mode_is_bvh(MODE) || MODE == MODE_REF) ? qc.sphereTests : 0u;
 #ifdef PT_STAMPS
@@ -628,6 +630,13 @@ constexpr uint32_t kWideStackLds = 16;          // 4-wide traversal: stack level
 // Lanes that must be out of work before the wave runs the refill code (render_body).  Scene in LDS: flat from 20 to 36 on
 // book-1, +2-4 % at 28-36 on the small scenes; tree in HBM (trips dear, refill cheap by comparison): 12.
 constexpr uint32_t kRefillMin = 28, kRefillMinHbm = 12;
+// A unit whose pool is empty is left (its unfinished paths ride along in the next unit and add their results with four
+// float atomics each) once at most this many paths are still under way; until then the unit runs on.  Book-1 1080p
+// 512 spp: 64 (always leave) / 32 / 24 / 16 / 12 / 8 / 0 (finish everything): 89.79 / 89.95 / 90.05 / 90.11 / 90.5 / 90.68 /
+// 95.16 ms with 17.5 / 5.2 / 3.0 / 1.4 / 0.9 / 0.4 / 0 million carried paths and 4.24 / - / 2.33 / - / 1.78 / - / 0.99 GB of
+// memory-side writes per launch (WRITE_SIZE: float atomics execute at the memory side; the tile flushes alone are the
+// 0.99 GB).  24 = the knee: a fifth of the scattered atomics for 0.3 % of the time.  Trees in HBM (trips dear): 32.
+constexpr uint32_t kCarryMax = 24, kCarryMaxHbm = 32;
 constexpr uint32_t kLeafBatch = 16; // BVH traversal: lanes gathered at leaves before the leaf code runs (pt_device.h, bvh_closest)
 // 4-wide nodes over single spheres (10^6 spheres 4K, 8 spp): a leaf step is one sphere test, so lanes wait for fewer
 // companions (leaf batch 1 / 4 / 8 / 16 / 32: 1106 / 1212 / 1242 / 1171 / 938 Msamples/s at exit 40) and the traversal
@@ -751,6 +760,8 @@ void fill_scene_args(SceneArgs* sc, const pth::Blob& b, const float4* dev, const
     sc->ns = 2 * b.npairs; sc->npairs = b.npairs; sc->ngroups = b.ngroups; sc->np = np; sc->idx_mask = b.idx_mask;
     sc->t0 = d->t0; sc->t1 = d->t1;
     sc->refill_min = kRefillMin;
+    sc->carry_max = kCarryMax;
+    if (const char* e = getenv("PT_CARRY_MAX")) { int v = atoi(e); if (v >= 0 && v <= 64) sc->carry_max = (uint32_t)v; } // tuning experiments only
     if (const char* e = getenv("PT_REFILL_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) sc->refill_min = (uint32_t)v; } // tuning experiments only
 }
 
@@ -921,6 +932,8 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         if (ctx->bvh_wide) ctx->sc_bvh.leaf_batch = kLeafBatchWide;
         const uint32_t refillLds = ctx->sc_bvh.refill_min; // (fill_scene_args: the default, or PT_REFILL_MIN)
         if (!getenv("PT_REFILL_MIN")) ctx->sc_bvh.refill_min = kRefillMinHbm;
+        const uint32_t carryLds = ctx->sc_bvh.carry_max; // (fill_scene_args: the default, or PT_CARRY_MAX)
+        if (!getenv("PT_CARRY_MAX")) ctx->sc_bvh.carry_max = kCarryMaxHbm;
         if (const char* e = getenv("PT_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->sc_bvh.leaf_batch = (uint32_t)v; } // tuning experiments only
         ctx->bvh_nodes = bv.n_nodes; ctx->bvh_depth = bv.depth;
         ctx->moving = bv.moving;
@@ -956,6 +969,7 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
             ctx->sc_bvh_lds = ctx->sc_bvh;
             ctx->sc_bvh_lds.exit_lanes = !resumable ? 0u : exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanes;
             ctx->sc_bvh_lds.refill_min = refillLds;
+            ctx->sc_bvh_lds.carry_max = carryLds;
             ctx->sc_bvh_lds.blob = ctx->blob_bvh_dev; ctx->sc_bvh_lds.blob_f4 = (uint32_t)(img.size() / 4);
             for (int k = 0; k < 4; ++k) ctx->sc_bvh_lds.bvh_off[k] = off[k];
             ctx->sc_bvh_lds.bvh = BvhView{nullptr, nullptr, nullptr, matInLds ? nullptr : ctx->mat_dev, bv.root_ref, bv.n_spheres, {0, 0, 0}, {1, 1, 1}};

@@ -732,7 +732,6 @@ PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live
         axis(ray.o.z, ray.d.z, b.gorg[2], b.gstep[2], r1z, n1z, r2z, n2z);
     }
     const bool anyFlat = cone_flat(ray.d.x) || cone_flat(ray.d.y) || cone_flat(ray.d.z);
-    const bool waveFlat = pt_ballot(anyFlat) != 0ull;   // ~1 wave in 6 holds such a ray at any time
     uint32_t level = ts.pk & 255u;
     uint32_t cur = ts.cur;
     bool leave = false;
@@ -758,21 +757,17 @@ PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live
                 const uint32_t cz[4] = {__float_as_uint(q0.z), __float_as_uint(q1.y), __float_as_uint(q2.x), __float_as_uint(q2.w)};
                 const uint32_t ref[4] = {__float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w)};
                 uint32_t key[4];
-                // (the rare flat-axis fix-up is compiled into a copy of its own behind a WAVE-uniform branch: left to the
-                // compiler it becomes six selects per box for every ray)
-                auto test4 = [&](auto flatTag)
-                {
-                    constexpr bool kFlat = decltype(flatTag)::value;
+                // (the rare flat-axis fix-up stays inside the one copy of the box code: a copy of its own behind a
+                // wave-uniform branch was measured -- same speed, but 69 instead of 12 spilled registers and 55 GB of
+                // scratch traffic per launch)
 #pragma unroll
-                    for (uint32_t k = 0; k < 4u; ++k)
-                    {
-                        float tnear;
-                        const bool hit = cone_planes<kFlat>((float)(cx[k] & 0xFFFFu), (float)(cx[k] >> 16), (float)(cy[k] & 0xFFFFu), (float)(cy[k] >> 16),
-                                                            (float)(cz[k] & 0xFFFFu), (float)(cz[k] >> 16), r1x, r1y, r1z, n1x, n1y, n1z, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &tnear);
-                        key[k] = (hit && ref[k] != kNoChild) ? ((__float_as_uint(fmaxf(tnear, 0.0f)) & ~3u) | k) : 0xFFFFFFFFu;
-                    }
-                };
-                if (waveFlat) test4(std::true_type{}); else test4(std::false_type{});
+                for (uint32_t k = 0; k < 4u; ++k)
+                {
+                    float tnear;
+                    const bool hit = cone_planes<true>((float)(cx[k] & 0xFFFFu), (float)(cx[k] >> 16), (float)(cy[k] & 0xFFFFu), (float)(cy[k] >> 16),
+                                                       (float)(cz[k] & 0xFFFFu), (float)(cz[k] >> 16), r1x, r1y, r1z, n1x, n1y, n1z, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &tnear);
+                    key[k] = (hit && ref[k] != kNoChild) ? ((__float_as_uint(fmaxf(tnear, 0.0f)) & ~3u) | k) : 0xFFFFFFFFu;
+                }
                 const uint32_t a0 = min(key[0], key[1]), a1 = max(key[0], key[1]), c0 = min(key[2], key[3]), c1 = max(key[2], key[3]);
                 const uint32_t s0 = min(a0, c0), m0 = max(a0, c0), m1 = min(a1, c1), s3 = max(a1, c1);
                 const uint32_t s1 = min(m0, m1), s2 = max(m0, m1);

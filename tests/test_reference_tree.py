@@ -147,3 +147,32 @@ def test_converged_image_in_reference_query_mode_reaches_the_noise_floor(rendere
         print(f"{key}: reference-query mode PSNR {p:.2f} dB (floor {floor_psnr:.2f}), mean rel err {m:.5f} (floor {floor_mre:.5f})")
         assert p >= floor_psnr - 0.75, (key, p, floor_psnr)
         assert m <= floor_mre * 1.1, (key, m, floor_mre)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(GOLDEN))
+def test_whole_paths_in_reference_query_mode_against_the_reference(renderer, oracle, golden_dir, name):
+    """cast_ray (main.cpp:171-307) end to end: with the reference's tree, its combine and each ray's slice of the
+    reference's own MT19937 streams as tape, EVERY path's radiance is the reference's -- the only difference left is the
+    multiplication order of the colours (D2: loop vs recursion), <= 1e-5 relative; against the oracle in the same mode
+    and order it is bit-equal.  (In the default closest-hit mode this holds only for the paths D1 does not touch.)"""
+    z, sa = _golden(golden_dir, name)
+    renderer.upload(to_pt_scene(sa))
+    renderer.build_reference_tree(0)
+    h = oracle.scene(sa)
+    oracle.scene_set_bvh(h, z["boxes"], z["links"])
+    try:
+        rays, times = z["rays"], z["times"]
+        for depth in (1, 5, 50):
+            ref = z[f"rgba_d{depth}"]
+            c_ref, _, _, o32, o64, _ = oracle.cast_rays_mt(h, rays, times, depth, 11, 3, po.QUERY_BVH_QUIRK, po.PRODUCT_RECURSIVE)
+            assert bit_equal(c_ref, ref)
+            t32, t64 = oracle.mt_f32(11, int(o32[-1]) + 64), oracle.mt_f64(3, int(o64[-1]) + 8)
+            c_gpu, segs = renderer.probe_paths(rays, times, depth, t32, o32, t64, o64, pt.FLAG_REFERENCE_QUERY)
+            assert ((segs >> 31) == 0).all()                                   # same decisions -> same draws: no tape overrun
+            c_it, over, _, _ = oracle.cast_rays_tape(h, rays, times, depth, t32, o32, t64, o64, po.QUERY_BVH_QUIRK, po.PRODUCT_ITERATIVE)
+            assert (over == 0).all() and bit_equal(c_gpu, c_it), (name, depth)
+            rel = np.abs(c_gpu.astype(np.float64) - ref.astype(np.float64)) / np.maximum(np.abs(ref.astype(np.float64)), 1e-6)
+            assert rel.max() <= 1e-5, (name, depth, float(rel.max()))
+    finally:
+        oracle.scene_free(h)

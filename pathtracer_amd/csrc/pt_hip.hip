@@ -1030,6 +1030,12 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
     unsigned long long* const stats_dev = fixed ? reinterpret_cast<unsigned long long*>(ctx->static_scratch) : ctx->stats_dev;
     const uint32_t stat_slots = fixed ? kStaticSlots : ctx->stat_slots;
     if (fixed && !ctx->static_scratch) { ctx->err = "the static scratch array has no address on this device"; return PT_ERR_HIP; }
+    // (PT_FLAG_REFERENCE_QUERY builds its tree on first use -- an allocation: the entry point that allocates nothing wants it built before)
+    if (fixed && (p->flags & PT_FLAG_REFERENCE_QUERY) && !ctx->has_ref)
+    {
+        ctx->err = "pt_hip_render_device_static: PT_FLAG_REFERENCE_QUERY needs pt_hip_build_reference_tree to have been called (this entry point does not allocate)";
+        return PT_ERR_UNSUPPORTED;
+    }
     int mode; const SceneArgs* sc; size_t lds = 0;
     // Workgroup shape: the waves of a workgroup share one staged copy of the scene, so bigger workgroups spend less LDS
     // per wave; take the shape that keeps the most waves resident on a CU (ties: the smaller workgroup).  With the tree

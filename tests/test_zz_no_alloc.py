@@ -25,11 +25,13 @@ def _frame(renderer, torch, static, w, h, s0, s1, depth, seed, flags):
 CALLS = [(1, 88, 56, 3, 48, 12), (1, 40, 24, 0, 20, 12), (3, 64, 36, 0, 45, 50), (1, 88, 56, 3, 48, 12)]
 
 
-@pytest.mark.parametrize("flags", [pt.FLAG_REPRODUCIBLE, pt.FLAG_REPRODUCIBLE | pt.FLAG_FORCE_BVH, 0, pt.FLAG_BRUTE_FORCE])
+@pytest.mark.parametrize("flags", [pt.FLAG_REPRODUCIBLE, pt.FLAG_REPRODUCIBLE | pt.FLAG_FORCE_BVH, 0, pt.FLAG_BRUTE_FORCE, pt.FLAG_REPRODUCIBLE | pt.FLAG_REFERENCE_QUERY])
 def test_static_entry_point_matches_render_device(renderer, flags):
     torch = pytest.importorskip("torch")
     for sid, w, h, s0, s1, depth in CALLS:
         renderer.upload(pt.Scene.builtin(sid, w / h))
+        if flags & pt.FLAG_REFERENCE_QUERY:
+            renderer.build_reference_tree(0)                                        # (an allocation: before the call that must not allocate)
         want, st_want = _frame(renderer, torch, False, w, h, s0, s1, depth, 5, flags)
         got, st_got = _frame(renderer, torch, True, w, h, s0, s1, depth, 5, flags)
         for k in ("samples", "segments", "kernel", "node_bytes"):
@@ -53,6 +55,11 @@ def test_static_entry_point_refuses_what_does_not_fit(renderer):
     with pytest.raises(pt.PtError) as e:
         renderer.render_device_static(p, acc.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert e.value.status == pt.PT_ERR_UNSUPPORTED and "static maximum" in str(e.value)
+    # PT_FLAG_REFERENCE_QUERY would have to build (allocate) its tree on first use: refused until the caller has built it
+    p = renderer.params(w, h, 0, 2, 5, seed=1, flags=pt.FLAG_REFERENCE_QUERY)
+    with pytest.raises(pt.PtError) as e:
+        renderer.render_device_static(p, acc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert e.value.status == pt.PT_ERR_UNSUPPORTED and "pt_hip_build_reference_tree" in str(e.value)
     # ... while the default mode needs no partial images and serves the same frame
     p = renderer.params(w, h, 0, 64, 5, seed=1, flags=0)
     renderer.render_device_static(p, acc.data_ptr(), torch.cuda.current_stream().cuda_stream)

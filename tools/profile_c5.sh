@@ -23,4 +23,6 @@ for PMC in \
   i=$((i+1))
   timeout -s KILL 300 rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- $CMD > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed: $PMC"; tail -3 $OUT/pmc$i.log; }
 done
+python3 $ROOT/tools/make_traffic.py $OUT scene5_n1000000_3840x2160_spp16_d50 $TAG || echo "traffic.json not refreshed"
+mkdir -p $ROOT/gpurun_out/profiles_new && cp $ROOT/profiles/traffic.json $ROOT/gpurun_out/profiles_new/traffic.json
 echo done

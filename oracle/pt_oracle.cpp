@@ -76,6 +76,7 @@ struct Rng
     virtual double f64() = 0; // random_f64()  utils.h:28-35
     virtual ~Rng() {}
     virtual void align() {}    // Philox only: skip to the next 4-word block (see PhiloxRng)
+    virtual bool pinhole_skips_lens() const { return false; } // Philox only: get_ray draws no lens point when lensRadius == 0
     uint64_t n32 = 0, n64 = 0; // draws taken, for tests that build tapes
     float f32(float lo, float hi) { return f32() * (hi - lo) + lo; } // utils.h:47-51
 };
@@ -134,6 +135,10 @@ struct PhiloxRng : Rng
     // Every scatter starts on a block boundary (a SIMT efficiency device of the MI355X build; part of the stream's
     // definition).  The reference's MT19937 stream has no such notion: MtRng / TapeRng ignore it.
     void align() override { k = (k + 3u) & ~3u; }
+    // A pinhole camera (lensRadius == 0) draws no lens point on this stream: camera.cpp:74 multiplies the point by zero,
+    // so the ray is the same and the sample starts with one Philox block instead of two (definition of the MI355X build's
+    // stream; the reference's own streams -- MtRng, TapeRng -- keep the loop).
+    bool pinhole_skips_lens() const override { return true; }
     float f32() override { ++n32; return (float)(word() >> 8) * 5.9604644775390625e-8f; }
     double f64() override
     {
@@ -254,7 +259,9 @@ Ray get_ray(const Camera& c, float u, float v, Rng& rng)                        
     V3 vertical = c.up;                                                            // camera.cpp:65 (NOT re-orthogonalised)
     V3 topLeft = add(sub(planePos, mul(mul(horizontal, width / 2.0f), c.focus)), mul(mul(vertical, height / 2.0f), c.focus)); // :69
     V3 rayTarget = sub(add(topLeft, mul(mul(mul(horizontal, u), width), c.focus)), mul(mul(mul(vertical, v), height), c.focus)); // :70
-    V3 pointOnLens = mul(random_point_in_unit_circle(rng), c.lensRadius);          // camera.cpp:74 (runs even if lensRadius == 0)
+    V3 disc = v3(0, 0, 0);
+    if (!(rng.pinhole_skips_lens() && c.lensRadius == 0.0f)) disc = random_point_in_unit_circle(rng); // camera.cpp:74 (runs even if lensRadius == 0)
+    V3 pointOnLens = mul(disc, c.lensRadius);
     V3 lensOffset = add(mul(horizontal, pointOnLens.x), mul(vertical, pointOnLens.y)); // camera.cpp:75
     V3 origin = add(c.pos, lensOffset);
     return make_ray(origin, normalize(sub(rayTarget, add(c.pos, lensOffset))), true); // camera.cpp:77

@@ -80,6 +80,7 @@ PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 
 struct PhiloxRng
 {
+    static constexpr bool kPinholeSkipsLens = true;  // get_ray: no lens draws when lensRadius == 0
     uint32_t k0, k1, pixel, sample, k;
     uint32_t b0, b1, b2, b3; // words k, k+1, .. of the current block, shifted down as they are consumed
     bool primed;             // the block of word k (k on a block boundary) is already in b0..b3
@@ -129,6 +130,7 @@ struct PhiloxRng
 // Explicit uniforms for the parity probes.
 struct TapeRng
 {
+    static constexpr bool kPinholeSkipsLens = false; // the reference's draw sequence, loop and all
     const float* t32; const double* t64; uint32_t n32, n64, i32, i64; bool over;
     PT_DEV void init(const float* a, uint32_t na, const double* b, uint32_t nb) { t32 = a; n32 = na; t64 = b; n64 = nb; i32 = i64 = 0; over = false; }
     PT_DEV float f32() { if (i32 >= n32) { over = true; ++i32; return 0.5f; } return t32[i32++]; }
@@ -210,7 +212,13 @@ template <class R> PT_DEV Ray get_ray(const DeviceCamera& c, float u, float v, R
     V3 topLeft = v3(c.topLeft[0], c.topLeft[1], c.topLeft[2]);
     V3 rayTarget = sub(add(topLeft, mul(mul(mul(horizontal, u), c.planeW), c.focus)),
                        mul(mul(mul(vertical, v), c.planeH), c.focus));                        // camera.cpp:70
-    V3 pointOnLens = mul(random_point_in_unit_circle(rng), c.lensRadius);                      // camera.cpp:74
+    // camera.cpp:74 runs its rejection loop even for a pinhole camera and multiplies the point by lensRadius = 0.  On the
+    // Philox stream (this build's own) a pinhole camera draws nothing here: the point is (0,0,0), the
+    // ray is the same (p * 0 = 0 whatever p) and a sample of a pinhole scene needs ONE Philox block instead of two.  The
+    // tape-driven probes, which replay the reference's draws, keep the loop.
+    V3 disc = v3(0.0f, 0.0f, 0.0f);
+    if (!(R::kPinholeSkipsLens && c.lensRadius == 0.0f)) disc = random_point_in_unit_circle(rng);
+    V3 pointOnLens = mul(disc, c.lensRadius);                                                  // camera.cpp:74
     V3 lensOffset = add(mul(horizontal, pointOnLens.x), mul(vertical, pointOnLens.y));         // camera.cpp:75
     Ray r;
     r.o = add(pos, lensOffset);

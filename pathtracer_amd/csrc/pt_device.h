@@ -453,27 +453,35 @@ PT_DEV bool cone_flat(float d) { return !(fabsf(d) > kConeEps * 1.001f); } // th
 // lo planes go with (r2, n2), hi planes with (r1, n1); the coordinates are floats (64-byte nodes) or grid cells (grid
 // nodes, whose grid is folded into the pairs).
 // A flat axis (|d| <= eps: d - eps < 0 < d + eps) bounds t from below with BOTH planes and not at all from above:
-//   FLAT_EXACT (trees in HBM): a side branch swaps the roles -- near = max of the two, far = +inf (~1e-3 of rays per axis).
-//     It matters there: a ray that runs parallel to a slab of 10^6 spheres, outside of it, is kept out of every box by
-//     that second bound; without it such a ray visits everything along its way, and a handful of those rays is the
-//     launch's tail (measured: C5 29 -> 146 ms).
-//   else (tree in LDS, a few hundred nodes): no branch; the hi-plane pair of a flat axis is (0, +big) (set up once per
-//     ray), i.e. that plane's value is +big -- its lower bound is dropped, a superset of the cone/box overlap.
+//   FLAT_EXACT (trees in HBM): near = max of the two, far = +big.  Branch-free and for free: with a per-ray, per-axis
+//     selector s = -big (ordinary axis) / +big (flat axis), near = med3(a0, a1, s) and far = max3(a0, a1, s) -- the same
+//     two instructions as min / max.  (Round 2 first had a side branch here: its seven selects per box were issued for
+//     every wave step, and half of all wave steps have a flat lane.)
+//     Exactness matters there: a ray that runs parallel to a slab of 10^6 spheres, outside of it, is kept out of every
+//     box by that second bound; without it such a ray visits everything along its way, and a handful of those rays is
+//     the launch's tail (measured: C5 29 -> 146 ms).
+//   else (tree in LDS, a few hundred nodes, no registers to spare for the selectors): the hi-plane pair of a flat axis
+//     is (0, +big) (set up once per ray), i.e. that plane's value is +big -- its lower bound is dropped, a superset of
+//     the cone/box overlap.
+PT_DEV float cone_flat_select(float d) { return cone_flat(d) ? kF32Max : -kF32Max; }
 template <bool FLAT_EXACT>
 PT_DEV bool cone_planes(float lox, float hix, float loy, float hiy, float loz, float hiz, float r1x, float r1y, float r1z, float n1x, float n1y, float n1z,
-                        float r2x, float r2y, float r2z, float n2x, float n2y, float n2z, bool anyFlat, V3 d, float best, float* tnear)
+                        float r2x, float r2y, float r2z, float n2x, float n2y, float n2z, float sx, float sy, float sz, float best, float* tnear)
 {
 #pragma clang fp contract(fast)
     const float a0 = lox * r2x + n2x, a1 = hix * r1x + n1x;
     const float b0 = loy * r2y + n2y, b1 = hiy * r1y + n1y;
     const float c0 = loz * r2z + n2z, c1 = hiz * r1z + n1z;
-    float nx = fminf(a0, a1), ny = fminf(b0, b1), nz = fminf(c0, c1);
-    float fx = fmaxf(a0, a1), fy = fmaxf(b0, b1), fz = fmaxf(c0, c1);
-    if (FLAT_EXACT && anyFlat)
+    float nx, ny, nz, fx, fy, fz;
+    if (FLAT_EXACT)
     {
-        if (cone_flat(d.x)) { nx = fx; fx = kF32Max; }
-        if (cone_flat(d.y)) { ny = fy; fy = kF32Max; }
-        if (cone_flat(d.z)) { nz = fz; fz = kF32Max; }
+        nx = __builtin_amdgcn_fmed3f(a0, a1, sx); ny = __builtin_amdgcn_fmed3f(b0, b1, sy); nz = __builtin_amdgcn_fmed3f(c0, c1, sz);
+        fx = fmaxf(fmaxf(a0, a1), sx); fy = fmaxf(fmaxf(b0, b1), sy); fz = fmaxf(fmaxf(c0, c1), sz);
+    }
+    else
+    {
+        nx = fminf(a0, a1); ny = fminf(b0, b1); nz = fminf(c0, c1);
+        fx = fmaxf(a0, a1); fy = fmaxf(b0, b1); fz = fmaxf(c0, c1);
     }
     const float tn = fmaxf(fmaxf(nx, ny), nz);
     const float tf = fminf(fminf(fx, fy), fz);
@@ -575,7 +583,8 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
     {
         cone_axis<FLAT_EXACT>(ray.o.x, ray.d.x, ix, nox, r2x, n2x); cone_axis<FLAT_EXACT>(ray.o.y, ray.d.y, iy, noy, r2y, n2y); cone_axis<FLAT_EXACT>(ray.o.z, ray.d.z, iz, noz, r2z, n2z);
     }
-    const bool anyFlat = CONE && FLAT_EXACT && (cone_flat(ray.d.x) || cone_flat(ray.d.y) || cone_flat(ray.d.z));
+    float sx = 0, sy = 0, sz = 0; // (FLAT_EXACT: the flat-axis selectors of cone_planes)
+    if (CONE && FLAT_EXACT) { sx = cone_flat_select(ray.d.x); sy = cone_flat_select(ray.d.y); sz = cone_flat_select(ray.d.z); }
     if constexpr (QN) // fold the node grid into the per-plane pairs: (r, n) -> (step * r, org * r + n)
     {
         nox = b.gorg[0] * ix + nox; noy = b.gorg[1] * iy + noy; noz = b.gorg[2] * iz + noz;
@@ -614,9 +623,9 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
                     const uint32_t lx = __float_as_uint(qa.x), ly = __float_as_uint(qa.y), lz = __float_as_uint(qa.z);
                     const uint32_t rx = __float_as_uint(qa.w), ry = __float_as_uint(qb.x), rz = __float_as_uint(qb.y);
                     hitL = cone_planes<FLAT_EXACT>((float)(lx & 0xFFFFu), (float)(lx >> 16), (float)(ly & 0xFFFFu), (float)(ly >> 16), (float)(lz & 0xFFFFu), (float)(lz >> 16),
-                                                   ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearL);
+                                                   ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, sx, sy, sz, cull, &nearL);
                     hitR = cone_planes<FLAT_EXACT>((float)(rx & 0xFFFFu), (float)(rx >> 16), (float)(ry & 0xFFFFu), (float)(ry >> 16), (float)(rz & 0xFFFFu), (float)(rz >> 16),
-                                                   ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearR);
+                                                   ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, sx, sy, sz, cull, &nearR);
                     refL = __float_as_uint(qb.z); refR = __float_as_uint(qb.w);
                 }
                 else
@@ -625,9 +634,9 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
                     // the two references are half of the node's last 16 bytes: an 8-byte load (from HBM the compiler would fetch all 16)
                     const float2 n3 = *reinterpret_cast<const float2*>(b.nodes + 4 * cur + 3);
                     // left box {n0.xyz .. n0.w, n1.x, n1.y}, right box {n1.z, n1.w, n2.x .. n2.yzw}
-                    hitL = CONE ? cone_planes<FLAT_EXACT>(n0.x, n0.w, n0.y, n1.x, n0.z, n1.y, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearL)
+                    hitL = CONE ? cone_planes<FLAT_EXACT>(n0.x, n0.w, n0.y, n1.x, n0.z, n1.y, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, sx, sy, sz, cull, &nearL)
                                 : box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ix, iy, iz, nox, noy, noz, cull, &nearL);
-                    hitR = CONE ? cone_planes<FLAT_EXACT>(n1.z, n2.y, n1.w, n2.z, n2.x, n2.w, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &nearR)
+                    hitR = CONE ? cone_planes<FLAT_EXACT>(n1.z, n2.y, n1.w, n2.z, n2.x, n2.w, ix, iy, iz, nox, noy, noz, r2x, r2y, r2z, n2x, n2y, n2z, sx, sy, sz, cull, &nearR)
                                 : box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ix, iy, iz, nox, noy, noz, cull, &nearR);
                     refL = __float_as_uint(n3.x); refR = __float_as_uint(n3.y);
                 }
@@ -704,18 +713,19 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
 // branch around that path is wave-uniform and all but never taken.
 constexpr uint32_t kNoChild = 0xFFFFFFFFu;
 constexpr uint32_t kOvfEntries = 72;   // + the LDS levels: trees of up to (stackCap + 72 - 1) / 3 wide levels (host checks)
+// (The LDS part is addressed as LDS and the overflow as private memory, explicitly: written through one generic pointer
+// the two stores merge into a flat_store of a selected address, which waits on both memory pipes.)
+typedef __attribute__((address_space(3))) uint32_t pt_lds_u32;
 PT_DEV void wide_push(const QueryCtx& q, uint32_t& level, uint32_t ref)
 {
     ++level;
-    if (pt_ballot(level >= q.stackCap) == 0ull) q.stack[level * 64u] = ref;
-    else if (level < q.stackCap) q.stack[level * 64u] = ref;
+    if (level < q.stackCap) ((pt_lds_u32*)q.stack)[level * 64u] = ref;
     else q.ovf[level - q.stackCap] = ref;
 }
 PT_DEV uint32_t wide_pop(const QueryCtx& q, uint32_t& level)
 {
     uint32_t r;
-    if (pt_ballot(level >= q.stackCap) == 0ull) r = q.stack[level * 64u];
-    else if (level < q.stackCap) r = q.stack[level * 64u];
+    if (level < q.stackCap) r = ((pt_lds_u32*)q.stack)[level * 64u];
     else r = q.ovf[level - q.stackCap];
     if (r != kBvhDone) --level;           // (level 0 holds the sentinel and stays)
     return r;
@@ -739,7 +749,7 @@ PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live
         axis(ray.o.y, ray.d.y, b.gorg[1], b.gstep[1], r1y, n1y, r2y, n2y);
         axis(ray.o.z, ray.d.z, b.gorg[2], b.gstep[2], r1z, n1z, r2z, n2z);
     }
-    const bool anyFlat = cone_flat(ray.d.x) || cone_flat(ray.d.y) || cone_flat(ray.d.z);
+    const float sx = cone_flat_select(ray.d.x), sy = cone_flat_select(ray.d.y), sz = cone_flat_select(ray.d.z);
     uint32_t level = ts.pk & 255u;
     uint32_t cur = ts.cur;
     bool leave = false;
@@ -765,15 +775,12 @@ PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live
                 const uint32_t cz[4] = {__float_as_uint(q0.z), __float_as_uint(q1.y), __float_as_uint(q2.x), __float_as_uint(q2.w)};
                 const uint32_t ref[4] = {__float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w)};
                 uint32_t key[4];
-                // (the rare flat-axis fix-up stays inside the one copy of the box code: a copy of its own behind a
-                // wave-uniform branch was measured -- same speed, but 69 instead of 12 spilled registers and 55 GB of
-                // scratch traffic per launch)
 #pragma unroll
                 for (uint32_t k = 0; k < 4u; ++k)
                 {
                     float tnear;
                     const bool hit = cone_planes<true>((float)(cx[k] & 0xFFFFu), (float)(cx[k] >> 16), (float)(cy[k] & 0xFFFFu), (float)(cy[k] >> 16),
-                                                       (float)(cz[k] & 0xFFFFu), (float)(cz[k] >> 16), r1x, r1y, r1z, n1x, n1y, n1z, r2x, r2y, r2z, n2x, n2y, n2z, anyFlat, ray.d, cull, &tnear);
+                                                       (float)(cz[k] & 0xFFFFu), (float)(cz[k] >> 16), r1x, r1y, r1z, n1x, n1y, n1z, r2x, r2y, r2z, n2x, n2y, n2z, sx, sy, sz, cull, &tnear);
                     key[k] = (hit && ref[k] != kNoChild) ? ((__float_as_uint(fmaxf(tnear, 0.0f)) & ~3u) | k) : 0xFFFFFFFFu;
                 }
                 const uint32_t a0 = min(key[0], key[1]), a1 = max(key[0], key[1]), c0 = min(key[2], key[3]), c1 = max(key[2], key[3]);

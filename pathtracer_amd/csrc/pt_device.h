@@ -753,9 +753,13 @@ PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live
     uint32_t level = ts.pk & 255u;
     uint32_t cur = ts.cur;
     bool leave = false;
+#ifdef PT_STAMPS
+    unsigned long long qs0 = 0, qs1 = 0, qs2 = 0;
+#endif
     for (;;)
     {
         // ---- inner steps
+        PT_QSTAMP(qs0);
         for (;;)
         {
             const bool atInner = !(cur & kBvhLeafFlag);                  // (the sentinel carries the leaf flag)
@@ -797,6 +801,10 @@ PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live
                 }
             }
         }
+        PT_QSTAMP(qs1);
+#ifdef PT_STAMPS
+        q.cycInner += qs1 - qs0;
+#endif
         if (leave) break;
         {
             const unsigned long long act = pt_ballot(cur != kBvhDone);
@@ -834,6 +842,10 @@ PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live
             }
         }
         if (atLeaf) cur = wide_pop(q, level);
+        PT_QSTAMP(qs2);
+#ifdef PT_STAMPS
+        q.cycLeaf += qs2 - qs1;
+#endif
     }
     ts.cur = cur; ts.best = best; ts.bestSlot = bestSlot;
     ts.pk = (ts.pk & ~255u) | level;

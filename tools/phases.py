@@ -4,13 +4,14 @@ import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pathtracer_amd as pt
 scene_id = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-w, h, spp, depth = 1920, 1080, int(sys.argv[2]) if len(sys.argv) > 2 else 64, 50
+w, h, spp, depth = int(os.environ.get("PH_W", "1920")), int(os.environ.get("PH_H", "1080")), int(sys.argv[2]) if len(sys.argv) > 2 else 64, 50
+n5 = int(os.environ.get("PH_SPHERES", "100000"))
 flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 for lib in ("libpt_hip_stamps.so", "libpt_hip.so"):
     pt._lib = None
     pt.load_library(os.path.join(os.path.dirname(pt.LIB_PATH), lib))
     r = pt.Renderer(0)
-    r.upload(pt.Scene.builtin(scene_id, w / h))
+    r.upload(pt.Scene.builtin(scene_id, w / h, n5))
     r.render(w, h, 0, spp, depth, flags=flags)
     r.render(w, h, 0, spp, depth, flags=flags)
     st = r.stats()

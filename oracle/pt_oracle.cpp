@@ -77,6 +77,7 @@ struct Rng
     virtual ~Rng() {}
     virtual void align() {}    // Philox only: skip to the next 4-word block (see PhiloxRng)
     virtual bool pinhole_skips_lens() const { return false; } // Philox only: get_ray draws no lens point when lensRadius == 0
+    virtual bool still_skips_time() const { return false; }   // Philox only: no time draw when t0 == t1
     uint64_t n32 = 0, n64 = 0; // draws taken, for tests that build tapes
     float f32(float lo, float hi) { return f32() * (hi - lo) + lo; } // utils.h:47-51
 };
@@ -139,6 +140,7 @@ struct PhiloxRng : Rng
     // so the ray is the same and the sample starts with one Philox block instead of two (definition of the MI355X build's
     // stream; the reference's own streams -- MtRng, TapeRng -- keep the loop).
     bool pinhole_skips_lens() const override { return true; }
+    bool still_skips_time() const override { return true; }
     float f32() override { ++n32; return (float)(word() >> 8) * 5.9604644775390625e-8f; }
     double f64() override
     {
@@ -471,7 +473,8 @@ V4 cast_ray(const Scene& sc, Ray ray, uint32_t maxDepth, float time, Rng& rng, T
 V4 pixel_sample(const Scene& sc, uint32_t px, uint32_t py, uint32_t w, uint32_t h, uint32_t depth, Rng& rng,
                 TraceOpts opt, uint32_t* segments)
 {
-    float rayTime = rng.f32(sc.t0, sc.t1);                                         // main.cpp:349 (always one draw)
+    // main.cpp:349 (always one draw; the Philox stream of the build skips it for a still scene: r * 0 + t0 = t0)
+    float rayTime = (rng.still_skips_time() && sc.t0 == sc.t1) ? sc.t0 : rng.f32(sc.t0, sc.t1);
     float u = ((float)px + rng.f32()) / (float)w;                                  // main.cpp:351
     float v = ((float)py - rng.f32()) / (float)h;                                  // main.cpp:352 (MINUS)
     Ray ray = get_ray(sc.cam, u, v, rng);                                          // main.cpp:354

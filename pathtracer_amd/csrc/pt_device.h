@@ -81,6 +81,7 @@ PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 struct PhiloxRng
 {
     static constexpr bool kPinholeSkipsLens = true;  // get_ray: no lens draws when lensRadius == 0
+    static constexpr bool kStillSkipsTime = true;    // begin_sample: no time draw when t0 == t1
     uint32_t k0, k1, pixel, sample, k;
     uint32_t b0, b1, b2, b3; // words k, k+1, .. of the current block, shifted down as they are consumed
     bool primed;             // the block of word k (k on a block boundary) is already in b0..b3
@@ -131,6 +132,7 @@ struct PhiloxRng
 struct TapeRng
 {
     static constexpr bool kPinholeSkipsLens = false; // the reference's draw sequence, loop and all
+    static constexpr bool kStillSkipsTime = false;
     const float* t32; const double* t64; uint32_t n32, n64, i32, i64; bool over;
     PT_DEV void init(const float* a, uint32_t na, const double* b, uint32_t nb) { t32 = a; n32 = na; t64 = b; n64 = nb; i32 = i64 = 0; over = false; }
     PT_DEV float f32() { if (i32 >= n32) { over = true; ++i32; return 0.5f; } return t32[i32++]; }
@@ -1257,7 +1259,11 @@ PT_DEV V4 cast_ray(const SceneView& s, QueryCtx& q, Ray ray, uint32_t maxDepth, 
 template <class R>
 PT_DEV Ray begin_sample(const DeviceCamera& cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h, float t0, float t1, R& rng, float* time)
 {
-    *time = rand_range(rng, t0, t1);                                     // main.cpp:349
+    // main.cpp:349 draws the time even for a still scene and scales the draw by t1 - t0 = 0.  On the Philox stream (this
+    // build's own) a still scene draws nothing here: r * 0 + t0 = t0 whatever r, and (u, v, first lens point) fill one
+    // Philox block exactly.  The tape-driven probes keep the draw.
+    if (R::kStillSkipsTime && t0 == t1) *time = t0;
+    else *time = rand_range(rng, t0, t1);                                // main.cpp:349
     float u = ((float)px + rng.f32()) / (float)w;                        // main.cpp:351
     float v = ((float)py - rng.f32()) / (float)h;                        // main.cpp:352
     return get_ray(cam, u, v, rng);                                      // main.cpp:354

@@ -78,6 +78,7 @@ struct Rng
     virtual void align() {}    // Philox only: skip to the next 4-word block (see PhiloxRng)
     virtual bool pinhole_skips_lens() const { return false; } // Philox only: get_ray draws no lens point when lensRadius == 0
     virtual bool still_skips_time() const { return false; }   // Philox only: no time draw when t0 == t1
+    virtual bool unit_sphere_point(V3*) { return false; }     // Philox only: its own form of utils.h:80-94 (see PhiloxRng)
     uint64_t n32 = 0, n64 = 0; // draws taken, for tests that build tapes
     float f32(float lo, float hi) { return f32() * (hi - lo) + lo; } // utils.h:47-51
 };
@@ -148,6 +149,41 @@ struct PhiloxRng : Rng
         uint64_t hi = word(), lo = word();
         return (double)(((hi << 32) | lo) >> 11) * 1.1102230246251565404e-16;
     }
+    // random_point_in_unit_sphere (utils.h:80-94) on this stream, one Philox block per trip of the loop (definition of
+    // the MI355X build's stream).  The reference draws z, y, x uniform on the 24-bit grid
+    // k * 2^-23 - 1 and keeps the point if norm(p) <= 1.  Here the top 9 bits of each coordinate (a cell of side 2^-8)
+    // and its low 15 bits are drawn separately: words 0..2 of a block are three attempts at a cell (z = bits 31..23,
+    // y = 22..14, x = 13..5), rejected outright when the cell's nearest corner is outside the sphere (no point of it can
+    // pass); the first surviving cell is completed with the block's one set of low bits (z: word 3 bits 31..17,
+    // y: 16..2, x: word 3 bits 1..0 above 13 of the 15 spare low bits of words 0..2) and takes the reference's test.
+    // A block without a surviving cell, or whose point fails, is spent; the next block starts afresh.  The accepted
+    // point is uniform over the grid points that pass the reference's test, as in the reference.
+    static bool cell_outside(uint32_t w)
+    {
+        auto a = [](uint32_t q) { return (q & 256u) ? (q & 255u) : (255u - q); }; // the cell's distance from the coordinate plane, in cells
+        uint32_t az = a(w >> 23), ay = a((w >> 14) & 511u), ax = a((w >> 5) & 511u);
+        return ax * ax + ay * ay + az * az > 65536u;                              // nearest corner: |p|^2 = sum / 2^16 > 1
+    }
+    bool unit_sphere_point(V3* out) override
+    {
+        for (;;)
+        {
+            align();
+            uint32_t w[4];
+            for (int i = 0; i < 4; ++i) w[i] = word();
+            int j = 0;
+            while (j < 3 && cell_outside(w[j])) ++j;
+            if (j == 3) continue;
+            const uint32_t spare = (w[0] & 31u) | ((w[1] & 31u) << 5) | ((w[2] & 31u) << 10);
+            const uint32_t kz = ((w[j] >> 23) << 15) | (w[3] >> 17);
+            const uint32_t ky = (((w[j] >> 14) & 511u) << 15) | ((w[3] >> 2) & 0x7FFFu);
+            const uint32_t kx = (((w[j] >> 5) & 511u) << 15) | ((w[3] & 3u) << 13) | (spare & 0x1FFFu);
+            // random_f32(-1, 1) = r * 2 - 1 with r = k * 2^-24 (utils.h:47-51): both scalings exact
+            V3 p = v3((float)kx * 5.9604644775390625e-8f * 2.0f + -1.0f, (float)ky * 5.9604644775390625e-8f * 2.0f + -1.0f,
+                      (float)kz * 5.9604644775390625e-8f * 2.0f + -1.0f);
+            if (norm(p) <= 1.0f) { *out = p; return true; }                        // utils.h:88
+        }
+    }
 };
 
 // ---------------------------------------------------------------- samplers (utils.h:71-138)
@@ -156,6 +192,7 @@ struct PhiloxRng : Rng
 // against libptref.so by tests/test_oracle_vs_reference.py).
 V3 random_point_in_unit_sphere(Rng& r)                                             // utils.h:80-94
 {
+    { V3 p; if (r.unit_sphere_point(&p)) return p; }                              // the Philox stream's own form (PhiloxRng)
     for (;;)
     {
         float z = r.f32(-1.0f, 1.0f), y = r.f32(-1.0f, 1.0f), x = r.f32(-1.0f, 1.0f); // utils.h:75-78,87
@@ -541,6 +578,13 @@ void oracle_philox_words(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_
 {
     PhiloxRng r(seed, pixel, sample);
     for (uint32_t i = 0; i < n; ++i) out[i] = r.word();
+}
+// n points of PhiloxRng::unit_sphere_point from the start of one stream; *words_used = stream position afterwards
+void oracle_philox_unit_sphere_points(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out, uint32_t* words_used)
+{
+    PhiloxRng r(seed, pixel, sample);
+    for (uint32_t i = 0; i < n; ++i) { V3 p = random_point_in_unit_sphere(r); out[3*i] = p.x; out[3*i+1] = p.y; out[3*i+2] = p.z; }
+    *words_used = r.k;
 }
 void oracle_philox_f32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out)
 {

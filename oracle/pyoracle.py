@@ -129,6 +129,11 @@ class Oracle:
         self.lib.oracle_philox_words(C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_uint32(n), _p(out))
         return out
 
+    def philox_unit_sphere_points(self, seed, pixel, sample, n):
+        out, used = np.zeros((n, 3), np.float32), C.c_uint32()
+        self.lib.oracle_philox_unit_sphere_points(C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_uint32(n), _p(out), C.byref(used))
+        return out, int(used.value)
+
     def philox_f32(self, seed, pixel, sample, n):
         out = np.zeros(n, np.float32)
         self.lib.oracle_philox_f32(C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_uint32(n), _p(out))

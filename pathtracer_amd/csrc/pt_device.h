@@ -125,6 +125,15 @@ struct PhiloxRng
     // align() + forget the rest of the block: the next draw refills anyway, and the four words stop being live state
     // (registers) across whatever comes in between -- the whole sphere query, in the render loop.
     PT_DEV void park() { align(); b0 = b1 = b2 = b3 = 0; primed = false; }
+    // The whole block at the (aligned) position, four words at once.
+    PT_DEV void take_block(uint32_t& w0, uint32_t& w1, uint32_t& w2, uint32_t& w3)
+    {
+        align();
+        if (!primed) fill();
+        primed = false;
+        w0 = b0; w1 = b1; w2 = b2; w3 = b3;
+        k += 4u;
+    }
     PT_DEV bool overrun() const { return false; }
 };
 
@@ -186,6 +195,54 @@ template <class R> PT_DEV V3 random_point_in_unit_sphere_bounded(R& r, uint32_t 
     }
     return p;
 }
+// The same sampler on the Philox stream: ONE block per trip of the loop instead of 3/4 block per point.
+// A uniform point of the cube [-1,1)^3 with 24-bit coordinates k * 2^-23 - 1 (what three draws of rand_pm1 give) is
+// drawn in two steps: the top 9 bits of each coordinate pick a cell of side 2^-8, the low 15 bits a point in the cell.
+// A cell whose nearest corner is outside the unit sphere holds no acceptable point -- it is rejected on its 27 bits,
+// and a 128-bit block holds three such attempts (words 0..2: z = bits 31..23, y = 22..14, x = 13..5) plus ONE set of
+// low bits (z: word 3 bits 31..17, y: 16..2, x: word 3 bits 1..0 and 13 of the 15 spare low bits of words 0..2) for
+// the first cell that survives.  The completed point takes the reference's test (norm(p) <= 1, utils.h:88); if it
+// fails (a boundary cell), or all three cells were outside, the block is spent and the next one starts afresh.  The
+// accepted point is uniform over the 24-bit points that pass the reference's test -- the reference loop's distribution
+// exactly; the lanes of a wave evaluate one Philox block per trip where twelve draws cost three.
+// (Cell test in integers: a = distance of the cell from the coordinate plane in cells, 0..255; the nearest corner has
+// |p|^2 = (ax^2 + ay^2 + az^2) / 2^16; above 1 + 2^-16 the float test norm_squared(p) <= 1 + 2^-23 fails for the whole cell.)
+PT_DEV bool philox_cell_outside(uint32_t w)
+{
+    const uint32_t f = w ^ 0x80402000u;       // top bit of each 9-bit field flipped: the field is the signed cell number
+    const int32_t tz = (int32_t)f >> 23, ty = (int32_t)(f << 9) >> 23, tx = (int32_t)(f << 18) >> 23;
+    const uint32_t az = (uint32_t)(tz ^ (tz >> 31)), ay = (uint32_t)(ty ^ (ty >> 31)), ax = (uint32_t)(tx ^ (tx >> 31));
+    return ax * ax + ay * ay + az * az > 65536u;
+}
+PT_DEV bool philox_sphere_block(PhiloxRng& r, V3* p)
+{
+    uint32_t w0, w1, w2, w3;
+    r.take_block(w0, w1, w2, w3);
+    const bool o0 = philox_cell_outside(w0), o1 = philox_cell_outside(w1), o2 = philox_cell_outside(w2);
+    const uint32_t w = !o0 ? w0 : (!o1 ? w1 : w2);
+    const uint32_t spare = (w0 & 31u) | ((w1 & 31u) << 5) | ((w2 & 31u) << 10);
+    const uint32_t kz = ((w >> 23) << 15) | (w3 >> 17);
+    const uint32_t ky = (((w >> 14) & 511u) << 15) | ((w3 >> 2) & 0x7FFFu);
+    const uint32_t kx = (((w >> 5) & 511u) << 15) | ((w3 & 3u) << 13) | (spare & 0x1FFFu);
+    // k * 2^-23 - 1: the product is exact, so one FMA rounds like the reference's multiply-then-add (see rand_pm1)
+    *p = v3(__builtin_fmaf((float)kx, 1.1920928955078125e-7f, -1.0f), __builtin_fmaf((float)ky, 1.1920928955078125e-7f, -1.0f),
+            __builtin_fmaf((float)kz, 1.1920928955078125e-7f, -1.0f));
+    return !(o0 && o1 && o2) && norm_squared(*p) <= kOnePlusUlp;          // == (norm(p) <= 1.0f), see above
+}
+// maxBlocks = 0: until a point is found; else *found = false after that many spent blocks (the caller tries again later).
+PT_DEV V3 random_point_in_unit_sphere_bounded(PhiloxRng& r, uint32_t maxBlocks, bool* found)
+{
+    V3 p = v3(0, 0, 0);
+    *found = true;
+    for (uint32_t n = 1;; ++n)
+    {
+        if (philox_sphere_block(r, &p)) break;
+        if (n == maxBlocks) { *found = false; break; }
+    }
+    return p;
+}
+PT_DEV V3 random_point_in_unit_sphere(PhiloxRng& r) { bool found; return random_point_in_unit_sphere_bounded(r, 0u, &found); }
+PT_DEV V3 random_unit_vector(PhiloxRng& r) { return normalize(random_point_in_unit_sphere(r)); }
 template <class R> PT_DEV V3 random_point_in_unit_circle(R& r)               // utils.h:124-138
 {
     V3 p;
@@ -1127,9 +1184,9 @@ PT_DEV double reflectance(double cosine, double refractRatio)
 }
 
 // Second half of cast_ray (main.cpp:219-298).  Returns false when the path ends at this hit.
-// maxAttempts > 0: the unit-sphere rejection loop gives up after that many points and the event is EV_PENDING (nothing
-// but the RNG has changed; the caller calls again for the same hit and the loop goes on where it stopped).  Four attempts
-// are twelve draws = three Philox blocks exactly, so the stream stands on a block boundary, where every scatter starts anyway.
+// maxAttempts > 0: the unit-sphere rejection loop gives up after that many Philox blocks (philox_sphere_block: up to three
+// points each) and the event is EV_PENDING (nothing but the RNG has changed; the caller calls again for the same hit and
+// the loop goes on where it stopped, on a block boundary, where every scatter starts anyway).
 enum : uint32_t { EV_PENDING = 5 };
 template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray* out, uint32_t* event, uint32_t maxAttempts = 0)
 {
@@ -1208,7 +1265,7 @@ PT_DEV V4 sky(const Ray& ray)                                            // main
 // pending != nullptr: bounded rejection loop (scatter's maxAttempts = kScatterAttempts); *pending = true means the hit
 // is not shaded yet -- ray, throughput and *terminal untouched, call again with the same hit.
 #ifndef PT_SCATTER_ATTEMPTS
-#define PT_SCATTER_ATTEMPTS 4
+#define PT_SCATTER_ATTEMPTS 2 // Philox blocks per trip: a block fails for 11 % of the lanes, two for 1.2 % (one block: -1 %)
 #endif
 constexpr uint32_t kScatterAttempts = PT_SCATTER_ATTEMPTS;
 template <class R>

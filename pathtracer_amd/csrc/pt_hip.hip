@@ -267,7 +267,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
                 rng.park(); // the next scatter aligns to a fresh block anyway: drop the buffered words from the live state
                 if constexpr (kBvh)
                 {
-                    // The unit-sphere rejection loop is left after kScatterAttempts points: a lane still without one
+                    // The unit-sphere rejection loop is left after kScatterAttempts Philox blocks: a lane still without a point
                     // keeps its hit (the traversal state is live anyway) and draws on in the wave's next trip.
                     ts.pk = pending ? (ts.pk | kPendingShade) : (ts.pk & ~kPendingShade);
                 }

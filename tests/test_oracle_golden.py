@@ -31,6 +31,46 @@ def test_philox_known_answers(oracle):
     assert (f64 == expect).all() and (f64 < 1).all() and (f64 >= 0).all()
 
 
+def test_philox_unit_sphere_points(oracle):
+    """random_point_in_unit_sphere on the Philox stream (one block per trip of the loop; definition in DESIGN.md section 4):
+    the oracle against the definition written out independently on the raw words, and the distribution against the
+    reference loop's -- uniform over the 24-bit grid points with norm(p) <= 1 (utils.h:80-94)."""
+    seed, px, smp, n = 0xC0FFEE, 12345, 9, 200000
+    pts, used = oracle.philox_unit_sphere_points(seed, px, smp, n)
+    assert used % 4 == 0
+    w = oracle.philox_words(seed, px, smp, used).reshape(-1, 4).astype(np.int64)
+
+    def dist(q):                                   # cells between the 9-bit cell q and the coordinate plane
+        return np.where(q >= 256, q - 256, 255 - q)
+
+    qz, qy, qx = w[:, :3] >> 23, (w[:, :3] >> 14) & 511, (w[:, :3] >> 5) & 511
+    outside = dist(qx) ** 2 + dist(qy) ** 2 + dist(qz) ** 2 > 65536
+    j = np.argmin(outside, axis=1)                 # first cell that is not outside (0 if there is none)
+    row = np.arange(len(w))
+    spare = (w[:, 0] & 31) | ((w[:, 1] & 31) << 5) | ((w[:, 2] & 31) << 10)
+    kz = (qz[row, j] << 15) | (w[:, 3] >> 17)
+    ky = (qy[row, j] << 15) | ((w[:, 3] >> 2) & 0x7FFF)
+    kx = (qx[row, j] << 15) | ((w[:, 3] & 3) << 13) | (spare & 0x1FFF)
+    p = (np.stack([kx, ky, kz], axis=1).astype(np.float64) * 2.0 ** -23 - 1.0).astype(np.float32)   # exact in f32
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    ok = ~outside.all(axis=1) & (np.sqrt(x * x + y * y + z * z, dtype=np.float32) <= np.float32(1.0))
+    assert ok.sum() == n and ok[-1]
+    assert bit_equal(pts, p[ok])
+    # a cell called outside holds no acceptable point: its nearest corner is already too far
+    assert (dist(qx) ** 2 + dist(qy) ** 2 + dist(qz) ** 2)[outside].min() > 65536
+    # blocks spent per point: 1 / (1 - 0.476^3 - boundary) = 1.12 (the plain loop: 1.91 points = 1.43 blocks of draws)
+    assert 1.10 < len(w) / n < 1.14
+    # uniform in the ball: E[x] = 0, E[x^2] = 1/5, E[|p|^2] = 3/5, P(|p| < 1/2) = 1/8, octants equally likely
+    d = pts.astype(np.float64)
+    assert np.abs(d.mean(axis=0)).max() < 4 * np.sqrt(0.2 / n)
+    assert np.abs((d * d).mean(axis=0) - 0.2).max() < 4 * np.sqrt((3 / 35 - 1 / 25) / n)
+    r2 = (d * d).sum(axis=1)
+    assert abs(r2.mean() - 0.6) < 4 * np.sqrt((3 / 7 - 9 / 25) / n)
+    assert abs((r2 < 0.25).mean() - 0.125) < 4 * np.sqrt(0.125 * 0.875 / n)
+    octant = ((d[:, 0] >= 0) * 1 + (d[:, 1] >= 0) * 2 + (d[:, 2] >= 0) * 4).astype(int)
+    assert np.abs(np.bincount(octant, minlength=8) / n - 0.125).max() < 4 * np.sqrt(0.125 * 0.875 / n)
+
+
 def test_primitives(oracle, golden_dir):
     z = g(golden_dir, "prims.npz")
     assert bit_equal(oracle.intersect_spheres(z["sphere_rays"], z["spheres"]), z["sphere_t"])

@@ -608,14 +608,17 @@ PT_DEV void trav_begin(const BvhView& b, float tLimit, int32_t planeIdx, bool li
     ts.cur = (live && b.n_spheres != 0) ? b.root_ref : kBvhDone;
 }
 
-// Advances the traversals of the wave.  minActive = 0: until every lane is done.  minActive > 0: the run is also left
-// as soon as fewer than minActive lanes are still traversing AND more live lanes than that have finished -- the
+// Advances the traversals of the wave.  exitRule = 0: until every lane is done.  Else (pack_exit_rule: minActive |
+// doneMul << 8) the run is also left as soon as fewer than minActive lanes are still traversing AND the live lanes that
+// have finished number more than 4 / doneMul of them (doneMul 4: more finished than traversing) -- the
 // stragglers keep their state (ts, LDS stack) and carry on in the next call, together with the rays the finished lanes
 // will have produced by then.  (Measured on book-1: 33 % of the inner steps and 44 % of the leaf steps of a
 // run-to-completion traversal are executed for fewer than 8 lanes.)
+constexpr uint32_t pack_exit_rule(uint32_t minActive, uint32_t doneMul) { return minActive ? (minActive | (doneMul << 8)) : 0u; }
 template <bool MOVING, bool CONE, bool QN, bool FLAT_EXACT>
-PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, QueryCtx& q, TravState& ts, uint32_t minActive)
+PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, QueryCtx& q, TravState& ts, uint32_t exitRule)
 {
+    const uint32_t minActive = exitRule & 255u, doneMul = exitRule >> 8; // (see pack_exit_rule)
     const uint32_t leafBatch = q.leafBatch;
 #ifdef PT_STAMPS
     unsigned long long qs0 = 0, qs1 = 0, qs2 = 0;
@@ -668,7 +671,7 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
             const uint32_t nInner = (uint32_t)__popcll(pt_ballot(atInner));
             const uint32_t nLeaf = (uint32_t)__popcll(pt_ballot(!atInner && cur != kBvhDone));
             if (nInner == 0u || nLeaf >= leafBatch) break;
-            if (nInner + nLeaf < minActive && (uint32_t)__popcll(pt_ballot(live && cur == kBvhDone)) > nInner + nLeaf) { leave = true; break; }
+            if (nInner + nLeaf < minActive && (uint32_t)__popcll(pt_ballot(live && cur == kBvhDone)) * doneMul > (nInner + nLeaf) * 4u) { leave = true; break; }
 #ifdef PT_STAMPS
             ++q.innerIters;
 #endif
@@ -718,7 +721,7 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
         {
             const unsigned long long act = pt_ballot(cur != kBvhDone);
             if (act == 0ull) break;
-            if ((uint32_t)__popcll(act) < minActive && (uint32_t)__popcll(pt_ballot(live && cur == kBvhDone)) > (uint32_t)__popcll(act)) break;
+            if ((uint32_t)__popcll(act) < minActive && (uint32_t)__popcll(pt_ballot(live && cur == kBvhDone)) * doneMul > (uint32_t)__popcll(act) * 4u) break;
         }
 #ifdef PT_STAMPS
         ++q.leafIters;
@@ -790,8 +793,9 @@ PT_DEV uint32_t wide_pop(const QueryCtx& q, uint32_t& level)
     return r;
 }
 template <bool MOVING>
-PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live, QueryCtx& q, TravState& ts, uint32_t minActive)
+PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live, QueryCtx& q, TravState& ts, uint32_t exitRule)
 {
+    const uint32_t minActive = exitRule & 255u, doneMul = exitRule >> 8; // (see pack_exit_rule)
     const uint32_t leafBatch = q.leafBatch;
     float best = ts.best;
     float cull = best * kCullSlack;      // (see bvh_run: boxes are culled with slack, the leaf test decides)
@@ -825,7 +829,7 @@ PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live
             const uint32_t nInner = (uint32_t)__popcll(pt_ballot(atInner));
             const uint32_t nLeaf = (uint32_t)__popcll(pt_ballot(!atInner && cur != kBvhDone));
             if (nInner == 0u || nLeaf >= leafBatch) break;
-            if (nInner + nLeaf < minActive && (uint32_t)__popcll(pt_ballot(live && cur == kBvhDone)) > nInner + nLeaf) { leave = true; break; }
+            if (nInner + nLeaf < minActive && (uint32_t)__popcll(pt_ballot(live && cur == kBvhDone)) * doneMul > (nInner + nLeaf) * 4u) { leave = true; break; }
             q.nodeVisits += nInner;                                      // wave-level tally
 #ifdef PT_STAMPS
             ++q.innerIters;
@@ -868,7 +872,7 @@ PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live
         {
             const unsigned long long act = pt_ballot(cur != kBvhDone);
             if (act == 0ull) break;
-            if ((uint32_t)__popcll(act) < minActive && (uint32_t)__popcll(pt_ballot(live && cur == kBvhDone)) > (uint32_t)__popcll(act)) break;
+            if ((uint32_t)__popcll(act) < minActive && (uint32_t)__popcll(pt_ballot(live && cur == kBvhDone)) * doneMul > (uint32_t)__popcll(act) * 4u) break;
         }
 #ifdef PT_STAMPS
         ++q.leafIters;

@@ -642,6 +642,7 @@ constexpr uint32_t kLeafBatch = 16; // BVH traversal: lanes gathered at leaves b
 // companions (leaf batch 1 / 4 / 8 / 16 / 32: 1106 / 1212 / 1242 / 1171 / 938 Msamples/s at exit 40) and the traversal
 // phase is left as soon as the finished lanes outnumber the others (exit 16 / 24 / 40-64: 1154 / 1187 / 1230-1245).
 constexpr uint32_t kLeafBatchWide = 8, kExitLanesWide = 48;
+constexpr uint32_t kExitMul = 4, kExitMulWide = 8; // traversal phase left when finished lanes x this > traversing lanes x 4 (wide: a third of the lanes finished)
 
 uint32_t pick_stride(uint32_t ntiles)
 {
@@ -928,7 +929,10 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
         if (const char* e = getenv("PT_EXIT_LANES")) { int v = atoi(e); if (v >= 0 && v <= 64) exitEnv = v; } // tuning experiments only
         const bool resumable = bv.n_spheres > kResumeMinSpheres;
 
-        ctx->sc_bvh.exit_lanes = !resumable ? 0u : exitEnv >= 0 ? (uint32_t)exitEnv : ctx->bvh_wide ? kExitLanesWide : kExitLanesHbm;
+        int exitMul = -1;
+        if (const char* e = getenv("PT_EXIT_MUL")) { int v = atoi(e); if (v >= 1 && v <= 255) exitMul = v; } // tuning experiments only
+        ctx->sc_bvh.exit_lanes = !resumable ? 0u : pack_exit_rule(exitEnv >= 0 ? (uint32_t)exitEnv : ctx->bvh_wide ? kExitLanesWide : kExitLanesHbm,
+                                                                 exitMul > 0 ? (uint32_t)exitMul : ctx->bvh_wide ? kExitMulWide : kExitMul);
         if (ctx->bvh_wide) ctx->sc_bvh.leaf_batch = kLeafBatchWide;
         const uint32_t refillLds = ctx->sc_bvh.refill_min; // (fill_scene_args: the default, or PT_REFILL_MIN)
         if (!getenv("PT_REFILL_MIN")) ctx->sc_bvh.refill_min = kRefillMinHbm;
@@ -967,7 +971,7 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
             }
             st = upload_f4(ctx, img.data(), img.size() * 4, &ctx->blob_bvh_dev); if (st != PT_OK) return st;
             ctx->sc_bvh_lds = ctx->sc_bvh;
-            ctx->sc_bvh_lds.exit_lanes = !resumable ? 0u : exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanes;
+            ctx->sc_bvh_lds.exit_lanes = !resumable ? 0u : pack_exit_rule(exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanes, exitMul > 0 ? (uint32_t)exitMul : kExitMul);
             ctx->sc_bvh_lds.refill_min = refillLds;
             ctx->sc_bvh_lds.carry_max = carryLds;
             ctx->sc_bvh_lds.blob = ctx->blob_bvh_dev; ctx->sc_bvh_lds.blob_f4 = (uint32_t)(img.size() / 4);

@@ -326,11 +326,13 @@ inline void quantise_nodes(const BvhData& in, NodeGrid* grid, std::vector<uint32
 // fetched only when the ray's cone touches its box (the 2-wide leaves fetch up to four spheres one after the other).
 //   node = 16 dwords:  child k (0..3): dwords 3k .. 3k+2 = {lo.x | hi.x << 16, lo.y | hi.y << 16, lo.z | hi.z << 16}
 //                      dwords 12..15 = references: inner -> wide node index; leaf -> kLeafFlag | (count-1) << 28 | first;
-//                      kNoChild = empty slot (its box is never looked at)
+//                      an empty slot (fewer than four children) repeats child 0's reference behind the box {cell 0 .. cell 0}
+//                      on every axis: a point in the grid's corner that a ray's cone all but never touches, and a
+//                      reference that is harmless when it does (the same sphere or subtree once more: same t, no change)
+//                      -- so the traversal tests four boxes and no "is there a child" flag
 // Built by collapsing the binary SAH tree: a node's two children are replaced, largest surface first, by THEIR children
 // until four are held (inner children only; leaves stay whole).  With `single` every multi-sphere leaf then becomes a
 // wide node of its own whose children are its spheres (or is inlined into its parent when there is room).
-constexpr uint32_t kNoChild = 0xFFFFFFFFu;
 struct WideData { std::vector<uint32_t> nodes; uint32_t n_nodes = 0, depth = 0, root_ref = 0; };
 inline void widen_nodes(const BvhData& in, const pt_scene_desc* d, bool single, NodeGrid* grid, WideData* out)
 {
@@ -475,7 +477,7 @@ inline void widen_nodes(const BvhData& in, const pt_scene_desc* d, bool single, 
                 q[12 + j] = wide[i].c[j].ref;
             }
             else
-                q[12 + j] = kNoChild;
+                q[12 + j] = wide[i].c[0].ref;   // (cells stay 0: see the layout comment)
         }
     }
 }

@@ -773,7 +773,6 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
 // would make a worst-case stack of 3 x depth + 1 entries -- LDS that most rays never touch and that costs resident
 // waves -- so only the first `stackCap` levels live in LDS and deeper ones in a per-lane scratch array (q.ovf); the
 // branch around that path is wave-uniform and all but never taken.
-constexpr uint32_t kNoChild = 0xFFFFFFFFu;
 constexpr uint32_t kOvfEntries = 72;   // + the LDS levels: trees of up to (stackCap + 72 - 1) / 3 wide levels (host checks)
 // (The LDS part is addressed as LDS and the overflow as private memory, explicitly: written through one generic pointer
 // the two stores merge into a flat_store of a selected address, which waits on both memory pipes.)
@@ -848,7 +847,7 @@ PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live
                     float tnear;
                     const bool hit = cone_planes<true>((float)(cx[k] & 0xFFFFu), (float)(cx[k] >> 16), (float)(cy[k] & 0xFFFFu), (float)(cy[k] >> 16),
                                                        (float)(cz[k] & 0xFFFFu), (float)(cz[k] >> 16), r1x, r1y, r1z, n1x, n1y, n1z, r2x, r2y, r2z, n2x, n2y, n2z, sx, sy, sz, cull, &tnear);
-                    key[k] = (hit && ref[k] != kNoChild) ? ((__float_as_uint(fmaxf(tnear, 0.0f)) & ~3u) | k) : 0xFFFFFFFFu;
+                    key[k] = hit ? ((__float_as_uint(fmaxf(tnear, 0.0f)) & ~3u) | k) : 0xFFFFFFFFu; // (an empty slot is a point box in the grid's corner, pt_bvh.h)
                 }
                 const uint32_t a0 = min(key[0], key[1]), a1 = max(key[0], key[1]), c0 = min(key[2], key[3]), c1 = max(key[2], key[3]);
                 const uint32_t s0 = min(a0, c0), m0 = max(a0, c0), m1 = min(a1, c1), s3 = max(a1, c1);

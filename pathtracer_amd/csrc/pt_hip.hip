@@ -1336,7 +1336,7 @@ int pt_bvh_selfcheck(const pt_scene_desc* d, uint64_t out8[8])
                 for (int j = 0; j < 4; ++j)
                 {
                     const uint32_t ref = q[12 + j];
-                    if (ref == pth::kNoChild) continue;
+                    if (j > 0 && ref == q[12] && q[3 * j] == 0u && q[3 * j + 1] == 0u && q[3 * j + 2] == 0u) continue; // an empty slot (pt_bvh.h)
                     float lo[3], hi[3];
                     for (int k = 0; k < 3; ++k)
                     {

@@ -1,0 +1,21 @@
+#!/bin/bash
+# End-of-round measurement set (one gpurun call): tools/final_measure.sh <tag>; everything lands under gpurun_out/final_<tag>/
+set -u
+TAG=$1
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/final_$TAG
+mkdir -p $OUT
+cd $ROOT
+timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > $OUT/gpu_tests.log 2>&1 || { tail -5 $OUT/gpu_tests.log; exit 1; }
+tail -1 $OUT/gpu_tests.log
+bash tools/profile.sh $TAG --steps 3 --warmup 1 > $OUT/profile.log 2>&1 || { tail -3 $OUT/profile.log; exit 1; }
+bash tools/profile_c5.sh ${TAG}_c5 > $OUT/profile_c5.log 2>&1 || { tail -3 $OUT/profile_c5.log; exit 1; }
+timeout -k 10 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -3 $OUT/bench.err; exit 1; }
+timeout -k 10 300 python bench.py --scene 5 --spheres 1000000 --width 3840 --height 2160 --spp-per-gpu 16 --cpu-spp 0 --steps 5 --warmup 1 > $OUT/c5_bench.json 2> $OUT/c5_bench.err || { tail -3 $OUT/c5_bench.err; exit 1; }
+timeout -k 10 300 python tools/bench_configs.py > $OUT/configs.jsonl 2>/dev/null || exit 1
+timeout -k 10 100 python tools/c5_spp.py 4 16 64 >> $OUT/configs.jsonl 2>/dev/null || exit 1
+timeout -k 10 600 python tools/report.py > $OUT/report.json 2> $OUT/report.err || { tail -3 $OUT/report.err; exit 1; }
+timeout -k 10 100 python tools/phases.py 1 128 > $OUT/phases_book1.txt 2>&1 || exit 1
+PH_W=3840 PH_H=2160 PH_SPHERES=1000000 timeout -k 10 200 python tools/phases.py 5 8 > $OUT/phases_c5.txt 2>&1 || exit 1
+PT_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --cpu-spp 0 --no-brute --steps 5 --warmup 1 > $OUT/bench_forcedist.json 2> $OUT/bench_forcedist.err || { tail -3 $OUT/bench_forcedist.err; exit 1; }
+echo all done

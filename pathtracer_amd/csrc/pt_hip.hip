@@ -711,7 +711,12 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
     } while (0)
 
 constexpr uint64_t kGuide = 48;        // guided schedule: a unit is at most 1/kGuide of a resident wave's even share of what is left (tile cost varies ~10x: measured optimum 32-64)
-constexpr uint32_t kMinChunkSpp = 8;   // never cut a tile's samples finer than this (every unit has fixed costs; measured: 4 and 16 are no better)
+constexpr uint32_t kMinChunkSpp = 4;   // never cut a tile's samples finer than this (every unit has fixed costs).  8 until the end of round 2: equal on
+                                       // long frames (1080p, 512 spp), but short ones want more units than waves -- 800x450 at 32 spp 1.26 -> 1.14 ms,
+                                       // 1080p at 16 spp 3.9 -> 3.5 ms (profiles/README.md); frames with less than kTinyFrame tile-samples per
+                                       // resident wave go down to 2
+constexpr uint64_t kTinyFrame = 16;
+constexpr uint32_t kFewSpheres = 16;
 constexpr uint32_t kMaxChunks = 4096;  // (the walk in the kernel is linear in the chunk index)
 constexpr uint64_t kMaxPartialBytes = 4ull << 30; // per-chunk partial images the context may hold (PT_FLAG_REPRODUCIBLE frames only)
 
@@ -1079,7 +1084,10 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
     const uint64_t slots = (uint64_t)wgPerCu * (uint64_t)ctx->num_cus * waves; // waves resident at once
     // The guided schedule (chunk_size above): a unit of the current chunk should be no more than 1/kGuide of an even
     // share of the remaining work per resident wave -- ratio = ntiles / (kGuide x slots), capped at 1/2 per chunk.
-    uint32_t minSpp = kMinChunkSpp;
+    // (scenes of a handful of spheres run a sample in a quarter of the time: a unit's fixed costs weigh as much more, and
+    // 8 stays their optimum: C2 22.6 against 20.7, C4 25.2 against 24.1 Gsamples/s)
+    const bool fewSpheres = ctx->desc.n_spheres <= kFewSpheres;
+    uint32_t minSpp = fewSpheres ? 2u * kMinChunkSpp : (uint64_t)a.ntiles * a.nspp < kTinyFrame * slots ? 2u : kMinChunkSpp;
     uint64_t guide = kGuide;
     if (const char* e = getenv("PT_CHUNK_MIN")) { int v = atoi(e); if (v >= 1) minSpp = (uint32_t)v; }  // tuning experiments only
     if (const char* e = getenv("PT_GUIDE")) { int v = atoi(e); if (v >= 1) guide = (uint64_t)v; }        // tuning experiments only

@@ -710,7 +710,8 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
         if (st_ != PT_OK) return st_;                                                                           \
     } while (0)
 
-constexpr uint64_t kGuide = 48;        // guided schedule: a unit is at most 1/kGuide of a resident wave's even share of what is left (tile cost varies ~10x: measured optimum 32-64)
+constexpr uint64_t kGuide = 24;        // guided schedule: a unit is at most 1/kGuide of a resident wave's even share of what is left (tile cost varies ~10x; 48 while the
+                                       // smallest chunk was 8 spp; with 4: 24 is +1 % at 512 spp, +2.5 % at 64-128 spp, 16 and below lose at 512)
 constexpr uint32_t kMinChunkSpp = 4;   // never cut a tile's samples finer than this (every unit has fixed costs).  8 until the end of round 2: equal on
                                        // long frames (1080p, 512 spp), but short ones want more units than waves -- 800x450 at 32 spp 1.26 -> 1.14 ms,
                                        // 1080p at 16 spp 3.9 -> 3.5 ms (profiles/README.md); frames with less than kTinyFrame tile-samples per
@@ -1088,7 +1089,7 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
     // 8 stays their optimum: C2 22.6 against 20.7, C4 25.2 against 24.1 Gsamples/s)
     const bool fewSpheres = ctx->desc.n_spheres <= kFewSpheres;
     uint32_t minSpp = fewSpheres ? 2u * kMinChunkSpp : (uint64_t)a.ntiles * a.nspp < kTinyFrame * slots ? 2u : kMinChunkSpp;
-    uint64_t guide = kGuide;
+    uint64_t guide = fewSpheres ? 2u * kGuide : kGuide; // (C2, 3 spheres at 1080p: 22.6 against 20.8 Gsamples/s)
     if (const char* e = getenv("PT_CHUNK_MIN")) { int v = atoi(e); if (v >= 1) minSpp = (uint32_t)v; }  // tuning experiments only
     if (const char* e = getenv("PT_GUIDE")) { int v = atoi(e); if (v >= 1) guide = (uint64_t)v; }        // tuning experiments only
     uint64_t ratio = ((uint64_t)a.ntiles << 16) / (guide * slots);

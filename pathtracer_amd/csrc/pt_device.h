@@ -576,6 +576,7 @@ struct QueryCtx // per-lane scratch and counters of the sphere query
     uint32_t* ovf; uint32_t stackCap;            // MODE_BVH_Q4: levels >= stackCap of the traversal stack live in this per-lane (scratch) array
 #ifdef PT_STAMPS
     uint32_t innerIters, leafIters;              // wave-level trips through the two kinds of traversal step
+    uint32_t leafSlotIters, leafExactIters;      // ... through the per-sphere loop of a leaf step, and how many of those ran the exact test
     unsigned long long cycInner, cycLeaf;        // s_memtime spent in them
 #endif
 };
@@ -734,6 +735,14 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
             const unsigned long long todo = pt_ballot(k < count);
             if (todo == 0ull) break;
             q.sphereTests += (uint32_t)__popcll(todo);                   // wave-level tally
+#ifdef PT_STAMPS
+            ++q.leafSlotIters;
+            {
+                bool ex = false;
+                if (k < count) { const float4 sd0 = b.sph[first + k]; V3 c0 = v3(sd0.x, sd0.y, sd0.z); if (MOVING) { const float4 vd0 = b.vel[first + k]; c0 = add(c0, mul(v3(vd0.x, vd0.y, vd0.z), time)); } ex = !sphere_clearly_missed(ray, c0, sd0.w); }
+                if (pt_ballot(ex) != 0ull) ++q.leafExactIters;
+            }
+#endif
             if (k < count)
             {
                 const uint32_t slot = first + k;

@@ -62,7 +62,7 @@ template <int MODE> __device__ __forceinline__ QueryCtx make_query(const SceneAr
     q.ovf = nullptr; q.stackCap = a.stack_entries;
     q.stack = stackBase; q.searched = 0; q.nodeVisits = 0; q.sphereTests = 0; q.leafBatch = a.leaf_batch;
 #ifdef PT_STAMPS
-    q.innerIters = 0; q.leafIters = 0; q.cycInner = 0; q.cycLeaf = 0;
+    q.innerIters = 0; q.leafIters = 0; q.cycInner = 0; q.cycLeaf = 0; q.leafSlotIters = 0; q.leafExactIters = 0;
 #endif
     return q;
 }
@@ -347,6 +347,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
 #ifdef PT_STAMPS
         slot[2] = cyc_refill; slot[3] = cyc_hit; slot[4] = cyc_shade;
         slot[9] = qc.innerIters; slot[10] = qc.leafIters; slot[11] = qc.cycInner; slot[12] = qc.cycLeaf;
+        slot[14] = qc.leafSlotIters; slot[15] = qc.leafExactIters;
 #endif
     }
 }

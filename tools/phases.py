@@ -19,7 +19,8 @@ for lib in ("libpt_hip_stamps.so", "libpt_hip.so"):
     wi = max(1, st["wave_iterations"])
     trav = {"inner_trips/iter": round(dc[9] / wi, 2), "leaf_trips/iter": round(dc[10] / wi, 2),
             "cyc_inner/iter": round(dc[11] / wi, 1), "cyc_leaf/iter": round(dc[12] / wi, 1),
-            "cyc/inner_trip": round(dc[11] / max(1, dc[9]), 1), "cyc/leaf_trip": round(dc[12] / max(1, dc[10]), 1)}
+            "cyc/inner_trip": round(dc[11] / max(1, dc[9]), 1), "cyc/leaf_trip": round(dc[12] / max(1, dc[10]), 1),
+            "slot_iters/leaf_trip": round(dc[14] / max(1, dc[10]), 2), "exact_iters/leaf_trip": round(dc[15] / max(1, dc[10]), 2), "lane_tests/slot_iter": round(st["sphere_tests"] / max(1, dc[14]), 1)}
     print(lib, "traversal", json.dumps(trav))
     tot = sum(st["phase_cycles"]) or 1
     print(lib, "flags", flags, json.dumps({"kernel": st["kernel"], "nodes/seg": round(st["node_visits"] / max(1, st["segments"]), 2), "tests/seg": round(st["sphere_tests"] / max(1, st["segments"]), 2), "kernel_ms": round(st["kernel_ms"], 3), "Msamples/s": round(st["samples"] / st["kernel_ms"] / 1e3, 1),

@@ -466,19 +466,33 @@ inline void widen_nodes(const BvhData& in, const pt_scene_desc* d, bool single, 
         return (uint32_t)g;
     };
     out->nodes.assign(16 * (size_t)wide.size(), 0u);
-    for (size_t i = 0; i < wide.size(); ++i)
-    {
-        uint32_t* q = out->nodes.data() + 16 * i;
-        for (uint32_t j = 0; j < 4; ++j)
+    auto quantise = [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i)
         {
-            if (j < wide[i].n)
+            uint32_t* q = out->nodes.data() + 16 * i;
+            for (uint32_t j = 0; j < 4; ++j)
             {
-                for (int k = 0; k < 3; ++k) q[3 * j + k] = cell(wide[i].c[j].box.lo[k], k, false) | cell(wide[i].c[j].box.hi[k], k, true) << 16;
-                q[12 + j] = wide[i].c[j].ref;
+                if (j < wide[i].n)
+                {
+                    for (int k = 0; k < 3; ++k) q[3 * j + k] = cell(wide[i].c[j].box.lo[k], k, false) | cell(wide[i].c[j].box.hi[k], k, true) << 16;
+                    q[12 + j] = wide[i].c[j].ref;
+                }
+                else
+                    q[12 + j] = wide[i].c[0].ref;   // (cells stay 0: see the layout comment)
             }
-            else
-                q[12 + j] = wide[i].c[0].ref;   // (cells stay 0: see the layout comment)
         }
+    };
+    // (ten million cell computations at 10^6 spheres: sliced over the builder's worker threads)
+    unsigned workers = std::thread::hardware_concurrency();
+    if (workers == 0) workers = 1;
+    if (workers > 16) workers = 16;
+    if (const char* e = getenv("PT_BUILD_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) workers = (unsigned)v; }
+    if (wide.size() < 65536 || workers == 1) quantise(0, wide.size());
+    else
+    {
+        std::vector<std::thread> th;
+        for (unsigned w = 0; w < workers; ++w) th.emplace_back(quantise, wide.size() * w / workers, wide.size() * (w + 1) / workers);
+        for (auto& t : th) t.join();
     }
 }
 

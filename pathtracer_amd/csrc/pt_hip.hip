@@ -643,7 +643,8 @@ constexpr uint32_t kLeafBatch = 16; // BVH traversal: lanes gathered at leaves b
 // companions (leaf batch 1 / 4 / 8 / 16 / 32: 1106 / 1212 / 1242 / 1171 / 938 Msamples/s at exit 40) and the traversal
 // phase is left as soon as the finished lanes outnumber the others (exit 16 / 24 / 40-64: 1154 / 1187 / 1230-1245).
 constexpr uint32_t kLeafBatchWide = 8, kExitLanesWide = 48;
-constexpr uint32_t kExitMul = 4, kExitMulWide = 8; // traversal phase left when finished lanes x this > traversing lanes x 4 (wide: a third of the lanes finished)
+constexpr uint32_t kExitMul = 4, kExitMulWide = 6; // traversal phase left when finished lanes x this > traversing lanes x 4 (wide: two finished for every three traversing)
+constexpr uint32_t kRefillMinWide = 8, kCarryMaxWide = 48; // wide-node kernel, swept together with kExitMulWide at the end of round 2: C5 1 599 -> 1 636 Msamples/s
 
 uint32_t pick_stride(uint32_t ntiles)
 {
@@ -942,9 +943,9 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
                                                                  exitMul > 0 ? (uint32_t)exitMul : ctx->bvh_wide ? kExitMulWide : kExitMul);
         if (ctx->bvh_wide) ctx->sc_bvh.leaf_batch = kLeafBatchWide;
         const uint32_t refillLds = ctx->sc_bvh.refill_min; // (fill_scene_args: the default, or PT_REFILL_MIN)
-        if (!getenv("PT_REFILL_MIN")) ctx->sc_bvh.refill_min = kRefillMinHbm;
+        if (!getenv("PT_REFILL_MIN")) ctx->sc_bvh.refill_min = ctx->bvh_wide ? kRefillMinWide : kRefillMinHbm;
         const uint32_t carryLds = ctx->sc_bvh.carry_max; // (fill_scene_args: the default, or PT_CARRY_MAX)
-        if (!getenv("PT_CARRY_MAX")) ctx->sc_bvh.carry_max = kCarryMaxHbm;
+        if (!getenv("PT_CARRY_MAX")) ctx->sc_bvh.carry_max = ctx->bvh_wide ? kCarryMaxWide : kCarryMaxHbm;
         if (const char* e = getenv("PT_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->sc_bvh.leaf_batch = (uint32_t)v; } // tuning experiments only
         ctx->bvh_nodes = bv.n_nodes; ctx->bvh_depth = bv.depth;
         ctx->moving = bv.moving;

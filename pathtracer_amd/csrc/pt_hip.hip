@@ -625,7 +625,7 @@ constexpr size_t kAccBytesPerWave = 64 * 16;
 constexpr uint32_t kMinResidentWaves = 16; // per CU: below this the LDS-resident tree loses to the tree in HBM
 // BVH traversal: bvh_run's minActive for the tree in LDS and in HBM (book-1 1080p: 105.1 -> 102.2 ms with 8, flat
 // from 6 to 12; 10^6 spheres 4K: 431 -> 594 -> 669 -> 700 Msamples/s with 0, 8, 16, 24); a single-leaf tree (up to 4 spheres) has no stragglers and skips it.
-constexpr uint32_t kExitLanes = 8, kExitLanesHbm = 24, kResumeMinSpheres = 4;
+constexpr uint32_t kExitLanes = 10, kExitLanesHbm = 24, kResumeMinSpheres = 4; // (tree in LDS: 8 until the joint sweep at the end of round 2; 10 with leaf batch 20: +0.2-0.5 % at 64-512 spp, C1 +5 %)
 constexpr uint32_t kGridNodeMinSpheres = 32768; // from here on the tree in HBM uses grid nodes (4-wide)
 constexpr uint32_t kWideStackLds = 16;          // 4-wide traversal: stack levels kept in LDS, deeper ones in per-lane scratch (C5, 37 levels needed: 10-20 in LDS 1297-1303 Msamples/s, 24: 1233 -- fewer resident waves)
 // Lanes that must be out of work before the wave runs the refill code (render_body).  Scene in LDS: flat from 20 to 36 on
@@ -638,6 +638,7 @@ constexpr uint32_t kRefillMin = 28, kRefillMinHbm = 12;
 // memory-side writes per launch (WRITE_SIZE: float atomics execute at the memory side; the tile flushes alone are the
 // 0.99 GB).  24 = the knee: a fifth of the scattered atomics for 0.3 % of the time.  Trees in HBM (trips dear): 32.
 constexpr uint32_t kCarryMax = 24, kCarryMaxHbm = 32;
+constexpr uint32_t kLeafBatchLds = 20;
 constexpr uint32_t kLeafBatch = 16; // BVH traversal: lanes gathered at leaves before the leaf code runs (pt_device.h, bvh_closest)
 // 4-wide nodes over single spheres (10^6 spheres 4K, 8 spp): a leaf step is one sphere test, so lanes wait for fewer
 // companions (leaf batch 1 / 4 / 8 / 16 / 32: 1106 / 1212 / 1242 / 1171 / 938 Msamples/s at exit 40) and the traversal
@@ -981,6 +982,7 @@ int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
             ctx->sc_bvh_lds = ctx->sc_bvh;
             ctx->sc_bvh_lds.exit_lanes = !resumable ? 0u : pack_exit_rule(exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanes, exitMul > 0 ? (uint32_t)exitMul : kExitMul);
             ctx->sc_bvh_lds.refill_min = refillLds;
+            if (!getenv("PT_LEAF_BATCH")) ctx->sc_bvh_lds.leaf_batch = kLeafBatchLds;
             ctx->sc_bvh_lds.carry_max = carryLds;
             ctx->sc_bvh_lds.blob = ctx->blob_bvh_dev; ctx->sc_bvh_lds.blob_f4 = (uint32_t)(img.size() / 4);
             for (int k = 0; k < 4; ++k) ctx->sc_bvh_lds.bvh_off[k] = off[k];

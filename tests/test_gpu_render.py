@@ -316,14 +316,16 @@ def test_command_line_renderer_matches_the_library(renderer, tmp_path):
         pytest.fail("pathtracer_amd/bin/pt_render is not built (make cli)")
     w, h, spp, depth, seed = 96, 54, 6, 8, 5
     out1, out2, sfile = tmp_path / "a.bmp", tmp_path / "b.bmp", tmp_path / "scene.txt"
-    common = ["--width", str(w), "--height", str(h), "--spp", str(spp), "--depth", str(depth), "--seed", str(seed)]
+    # PT_FLAG_REPRODUCIBLE on both sides: the default mode's sums differ in their last bits from run to run (the order
+    # of the float additions into a pixel is the run's), and a last bit can move a truncated 8-bit channel by one
+    common = ["--width", str(w), "--height", str(h), "--spp", str(spp), "--depth", str(depth), "--seed", str(seed), "--flags", str(pt.FLAG_REPRODUCIBLE)]
     r1 = subprocess.run([exe, "--scene", "1", "--save-scene", str(sfile), "--out", str(out1)] + common, capture_output=True, text=True, timeout=120)
     assert r1.returncode == 0, r1.stderr
     assert "Time elapsed" in r1.stdout
     r2 = subprocess.run([exe, "--scene-file", str(sfile), "--out", str(out2)] + common, capture_output=True, text=True, timeout=120)
     assert r2.returncode == 0, r2.stderr
     renderer.upload(pt.Scene.builtin(1, w / h))
-    px = pt.resolve(renderer.render(w, h, 0, spp, depth, seed=seed), spp)
+    px = pt.resolve(renderer.render(w, h, 0, spp, depth, seed=seed, flags=pt.FLAG_REPRODUCIBLE), spp)
     expect = bytes(pt.bmp_header(w, h)) + pt.pack_bgra(px).astype("<u4").tobytes()
     assert out1.read_bytes() == expect
     assert out2.read_bytes() == expect

@@ -23,16 +23,16 @@ $(BINDIR)/pt_render: $(HOST)/pt_main.cpp include/pt_hip.h $(LIBDIR)/libpt_hip.so
 	@mkdir -p $(BINDIR)
 	g++ -O2 -std=c++17 -Wall $< -o $@ -L$(LIBDIR) -lpt_hip -pthread -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,/opt/rocm/lib
 
-$(LIBDIR)/pt_hip.o: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h $(CSRC)/pt_bvh.h include/pt_hip.h
+$(LIBDIR)/pt_hip.o: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h $(CSRC)/pt_bvh.h $(CSRC)/pt_guard.h include/pt_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/pt_world.o: $(HOST)/pt_world.cpp $(HOST)/pt_world.h include/pt_hip.h
+$(LIBDIR)/pt_world.o: $(HOST)/pt_world.cpp $(HOST)/pt_world.h $(CSRC)/pt_guard.h include/pt_hip.h
 	@mkdir -p $(LIBDIR)
 	g++ $(CXXFLAGS) -c $< -o $@
 
 # pt_node.hip: host-only code (contexts, streams, RCCL bound with dlopen); hipcc for the HIP / RCCL headers
-$(LIBDIR)/pt_node.o: $(CSRC)/pt_node.hip include/pt_hip.h
+$(LIBDIR)/pt_node.o: $(CSRC)/pt_node.hip $(CSRC)/pt_guard.h include/pt_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -fPIC -Wall -c $< -o $@
 
@@ -49,7 +49,20 @@ isa: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h
 clean:
 	rm -rf $(LIBDIR) $(BINDIR) ; $(MAKE) -C oracle clean
 
-.PHONY: all lib cli oracle isa clean
+# Host-side hardening: the scene model, the scene-file parser, both tree builders and the
+# widening under AddressSanitizer + UBSan (host code only: plain g++, no HIP), and allocation / thread-spawn fault
+# injection against the built library.  tests/test_host_hardening.py builds and runs both.
+SANDIR := tests/native/build
+asan: $(SANDIR)/host_sanitize
+$(SANDIR)/host_sanitize: tests/native/host_sanitize.cpp $(HOST)/pt_world.cpp $(HOST)/pt_world.h $(CSRC)/pt_bvh.h $(CSRC)/pt_guard.h include/pt_hip.h
+	@mkdir -p $(SANDIR)
+	g++ -O1 -g -std=c++17 -Wall -ffp-contract=off -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer tests/native/host_sanitize.cpp $(HOST)/pt_world.cpp -o $@ -pthread
+oom: $(SANDIR)/host_oom
+$(SANDIR)/host_oom: tests/native/host_oom.cpp include/pt_hip.h $(LIBDIR)/libpt_hip.so
+	@mkdir -p $(SANDIR)
+	g++ -O1 -g -std=c++17 -Wall tests/native/host_oom.cpp -o $@ -L$(LIBDIR) -lpt_hip -pthread -Wl,-rpath,'$$ORIGIN/../../../$(LIBDIR)' -Wl,-rpath-link,/opt/rocm/lib
+
+.PHONY: all lib cli oracle isa clean asan oom
 
 # Diagnostic build with in-kernel s_memtime stamps (never shipped, never benchmarked: read its SHARES, not its speed).
 stamps: $(CSRC)/pt_hip.hip $(CSRC)/pt_device.h $(CSRC)/pt_host.h $(LIBDIR)/pt_world.o $(LIBDIR)/pt_node.o

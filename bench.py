@@ -6,20 +6,27 @@ Workload : BASELINE.json configs[2] geometry -- init_test_scene_1 (book-1 final:
            depth 50, 512 spp PER GPU (4096 spp split across 8 GPUs) -- so per-GPU work is fixed as N grows (weak
            scaling): rank r renders global sample indices [r*512, (r+1)*512) of every pixel.
 Step     : one complete frame: render kernel -> (N>1) RCCL all-reduce of the float accumulation buffer -> device
-           resolve (clamp(mean), gamma, BGRA pack).  Scene and output buffers are resident in HBM before the timed
-           region; the PCIe read-back of the 8 MB BGRA image is outside it (DESIGN.md quotes the PCIe-inclusive rate).
-One rank per GPU; for N>1 launch with torch.distributed.run (reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+           resolve (clamp(mean), gamma, BGRA pack) -> read-back of the packed image to pinned host memory on rank 0
+           (the reference's timed span, main.cpp:412-481, ends with the pixels in host memory).  Scene and
+           working buffers are resident in HBM before the timed region.
+One rank per GPU.  N>1: launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env), or --
+with no WORLD_SIZE in the env -- bench.py starts the N ranks itself as child processes BEFORE anything touches a GPU
+(the parent imports neither torch nor the library; it exits non-zero if any rank does).
+--spp-total T: strong scaling -- T samples per pixel split over the ranks (C3: --spp-total 4096).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
+PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz): packed v_pk_fma_f32
+PEAK_FP32_UNPACKED = 78.6  # ... and with one FP32 FMA per lane per issue (SURVEY.md 8(d): report against both)
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
@@ -43,6 +50,11 @@ def cpu_baseline(scene_id, w, h, depth, spp, threads, n_spheres=0):
     import pathtracer_amd as pt
     from tests._util import to_scene_arrays
     sa = to_scene_arrays(pt.Scene.builtin(scene_id, w / h, n_spheres))
+    o3 = None
+    if not po.Ref.available():
+        print("bench.py: oracle/_ref/libptref.so (the compiled reference) is ABSENT -- it is built from /root/reference by "
+              "`make -C oracle`, which this tree has not seen; cpu_baseline falls back to kind \"port\" (our CPU restatement)",
+              file=sys.stderr)
     if po.Ref.available() and sa.n_spheres <= 4192:   # the reference's World holds 4192 objects (render_world.h:85)
         R = po.Ref()
         hs = R.scene_from_arrays(sa)
@@ -50,6 +62,18 @@ def cpu_baseline(scene_id, w, h, depth, spp, threads, n_spheres=0):
         secs, _ = R.render(hs, w, h, spp, depth, threads)
         R.scene_free(hs)
         kind = "reference"
+        # the courtesy figure SURVEY.md 8(d) asks for: the same reference sources at -O3 -march=native (the reference's
+        # own flag is /O2, build.bat:13), when oracle/Makefile built that flavour for THIS machine's CPU
+        if po.Ref.available(flavour="o3"):
+            try:
+                R3 = po.Ref(flavour="o3")
+                h3 = R3.scene_from_arrays(sa)
+                R3.build_bvh(h3, 0)
+                s3, _ = R3.render(h3, w, h, spp, depth, threads)
+                R3.scene_free(h3)
+                o3 = {"value": round(w * h * spp / s3 / 1e6, 4), "flags": "-O3 -march=native"}
+            except Exception as e:  # noqa: BLE001 - e.g. built for another CPU
+                o3 = {"value": None, "error": str(e)[:80]}
     else:
         O = po.Oracle()
         hs = O.scene(sa)
@@ -57,7 +81,8 @@ def cpu_baseline(scene_id, w, h, depth, spp, threads, n_spheres=0):
         O.scene_free(hs)
         kind = "port"
     return {"value": round(w * h * spp / secs / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": kind,
-            "sample": f"scene {scene_id} {w}x{h} depth {depth}, {spp} spp ({w * h * spp / 1e6:.1f} Msamples, {secs:.1f} s wall)"}
+            "sample": f"scene {scene_id} {w}x{h} depth {depth}, {spp} spp ({w * h * spp / 1e6:.1f} Msamples, {secs:.1f} s wall)",
+            "flags": "-O2 (the reference's /O2, build.bat:13)" if kind == "reference" else "-O2", "o3_native": o3}
 
 
 def host_threads():
@@ -76,6 +101,43 @@ def host_threads():
     return n, {"os_cpu_count": os.cpu_count(), "affinity": n_aff, "cgroup_quota": quota}
 
 
+def launch_ranks(n, argv):
+    """N > 1 with no launcher above us: start the N ranks as fresh child processes, each with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in its environment (what torch.distributed.run would set).  Runs BEFORE anything in this process
+    has touched a GPU -- this parent imports neither torch nor libpt_hip.so -- and replaces nothing: it waits for its
+    children and exits non-zero if any of them does (the others are then stopped)."""
+    assert "torch" not in sys.modules and "pathtracer_amd" not in sys.modules
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PT_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    pending = dict(enumerate(procs))
+    while pending:
+        for r, pr in list(pending.items()):
+            code = pr.poll()
+            if code is None:
+                continue
+            del pending[r]
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr)
+                for other in pending.values():
+                    other.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def pick_device(local_rank, n_visible):
+    """The GPU of a rank: LOCAL_RANK when the process sees the node's GPUs, LOCAL_RANK modulo what it does see when a
+    launcher masked the devices per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES: each rank then sees ONE device, 0)."""
+    return local_rank % n_visible if n_visible > 0 else -1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,11 +148,15 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp-per-gpu", type=int, default=512)
+    ap.add_argument("--spp-total", type=int, default=0, help="strong scaling: this many samples per pixel split over the ranks (C3: 4096); 0 = weak (--spp-per-gpu each)")
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-brute", action="store_true", help="skip the extra launch of the brute-force kernel (profiling runs)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))   # (no GPU call has been made in this process)
 
     import torch
     import torch.distributed as dist
@@ -98,31 +164,53 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count wins nothing here, give both the same N", file=sys.stderr)
         sys.exit(2)
-    if not torch.cuda.is_available() or pt.device_count() <= local_rank:
+    n_visible = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+    dev_index = pick_device(local_rank, n_visible)
+    if dev_index < 0 or not torch.cuda.is_available() or pt.device_count() <= dev_index:
         print("bench.py: no HIP device visible -- the product path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world > n_visible and n_visible > 1 and rank == 0:
+        print(f"bench.py: {world} ranks share {n_visible} visible GPUs", file=sys.stderr)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # PT_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, all-reduce, barrier) with a single rank too -- a
     # rehearsal of the N > 1 plumbing on a one-GPU box; the numbers of such a run are N = 1 numbers.
     use_dist = world > 1 or os.environ.get("PT_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        # nccl == RCCL on ROCm.  PT_BENCH_BACKEND=gloo: rehearsal of the N > 1 plumbing (launcher, slices, reduce, max over
+        # ranks) on a box with fewer GPUs than ranks -- RCCL refuses two ranks on one device; such a line says so.
+        backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    w, h, S, depth = args.width, args.height, args.spp_per_gpu, args.depth
+    w, h, depth = args.width, args.height, args.depth
+    # this rank's slice of the global sample indices: weak = S each, strong = its part of --spp-total
+    if args.spp_total > 0:
+        spp_all = args.spp_total
+        s_begin, s_end = pt.spp_slice(0, spp_all, world, rank)
+    else:
+        spp_all = args.spp_per_gpu * world
+        s_begin, s_end = rank * args.spp_per_gpu, (rank + 1) * args.spp_per_gpu
+    S = s_end - s_begin
+    if S <= 0:
+        print(f"bench.py: rank {rank} has no samples ({spp_all} spp over {world} ranks)", file=sys.stderr)
+        sys.exit(2)
     scene = pt.Scene.builtin(args.scene, w / h, args.spheres)
-    r = pt.Renderer(local_rank)
+    r = pt.Renderer(dev_index)
     r.upload(scene)
     accum = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
     bgra = torch.empty((h, w), dtype=torch.int32, device=dev)
-    params = r.params(w, h, rank * S, (rank + 1) * S, depth, seed=args.seed)
+    bgra_host = torch.empty((h, w), dtype=torch.int32, pin_memory=True) if rank == 0 else None
+    params = r.params(w, h, s_begin, s_end, depth, seed=args.seed)
     stream = torch.cuda.current_stream(dev)
 
     def step(ev=None):
@@ -134,7 +222,8 @@ def main():
         if use_dist:
             dist.all_reduce(accum, op=dist.ReduceOp.SUM)  # float accumulation buffer over xGMI, before tonemapping
         if rank == 0:
-            r.resolve_device(accum.data_ptr(), w * h, S * world, 0, bgra.data_ptr(), stream.cuda_stream)
+            r.resolve_device(accum.data_ptr(), w * h, spp_all, 0, bgra.data_ptr(), stream.cuda_stream)
+            bgra_host.copy_(bgra, non_blocking=True)   # 4 B/pixel over PCIe, inside the timed step
 
     def fence():
         if use_dist:
@@ -164,9 +253,20 @@ def main():
     else:
         segs, smps, nvis, stest = float(st["segments"]), float(st["samples"]), float(st["node_visits"]), float(st["sphere_tests"])
 
-    host_img = bgra.cpu() if rank == 0 else None  # outside the timed region (PCIe)
+    host_img = bgra_host if rank == 0 else None
     if rank == 0:
-        samples_per_step = w * h * S * world
+        # what the read-back costs, by itself: the packed image (in the step) and the float sums it replaces (8f rank 1)
+        def timed_copy(dst, src):
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t) * 1e3
+        accum_host = torch.empty((h, w, 4), dtype=torch.float32, pin_memory=True)
+        readback_ms = {"bgra_4B_per_pixel": round(min(timed_copy(bgra_host, bgra) for _ in range(3)), 3),
+                       "f32_sums_16B_per_pixel": round(min(timed_copy(accum_host, accum) for _ in range(3)), 3)}
+        del accum_host
+        samples_per_step = w * h * spp_all
         value = samples_per_step * args.steps / elapsed / 1e6
         sbar = segs / smps
         moving = scene.vel is not None
@@ -175,17 +275,23 @@ def main():
         # an inner-node visit tests every child box it holds (2 or 4 x 32 FLOP); leaf tests are per sphere
         f_sample = flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving, float(st["node_width"] or 2) * nvis / segs, stest / segs) if is_bvh else \
             flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving)
-        # roofline of the dominant kernel (k_render), per launch on one GPU
-        achieved = (w * h * S) * f_sample / (kernel_ms * 1e-3) / 1e12
+        # roofline of the dominant kernel (k_render), per launch on one GPU (mean over the ranks' launches)
+        achieved = (samples_per_step / world) * f_sample / (kernel_ms * 1e-3) / 1e12
         # HBM bytes per launch come from PMC passes (rocprofv3 cannot run inside this process): tools/profile.sh runs
         # THIS command under the counters and writes profiles/traffic.json in the same run that produces the kept
         # summary; the line says which run that was.  No entry for this workload -> null.
-        traffic, traffic_run = None, None
+        traffic, traffic_run, retired = None, None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
                 t = json.load(open(tf)).get(f"scene{args.scene}{'_n' + str(args.spheres) if args.spheres else ''}_{w}x{h}_spp{S}_d{depth}", {})
                 traffic, traffic_run = t.get("hbm_bytes_per_launch"), t.get("run")
+                # FP32 work the SIMDs RETIRED in that profiled launch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 x 64 lanes x the
+                # launch's lane activity, FMA = 2), over the profiled kernel time: the counters' own fraction of the peak
+                if t.get("retired_fp32_flop_per_launch") and t.get("kernel_ns"):
+                    rt = t["retired_fp32_flop_per_launch"] / (t["kernel_ns"] * 1e-9) / 1e12
+                    retired = {"frac": round(rt / PEAK_FP32_TFLOPS, 4), "achieved": round(rt, 2), "lane_activity": t.get("lane_activity"),
+                               "valu_insts_per_launch": t.get("valu_insts_per_launch"), "run": t.get("run")}
             except Exception:  # noqa: BLE001
                 traffic = None
         # The formulation SURVEY.md 8(d) prices (brute force over the LDS-resident scene, packed FP32), MEASURED: one
@@ -204,7 +310,8 @@ def main():
             except pt.PtError:
                 brute = None   # the scene has no brute-force image in LDS
         roof = {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic, "traffic_run": traffic_run,
+                "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "frac_unpacked": round(achieved / PEAK_FP32_UNPACKED, 4),
+                "retired": retired, "traffic": traffic, "traffic_run": traffic_run,
                 "kernel": kernel_name, "flop_per_sample": round(f_sample, 1),
                 "box_tests_per_segment": round((st["node_width"] or 2) * nvis / segs, 2) if is_bvh else None,
                 "leaf_sphere_tests_per_segment": round(stest / segs, 2) if is_bvh else None,
@@ -214,28 +321,33 @@ def main():
                         "share of peak spent on algorithmically necessary FP32 work; brute_force_kernel is the measured figure of "
                         "the brute-force formulation 8(d) prices (its own FLOPs over its own time)"}
         if st["kernel"] == 1 and scene.n_spheres >= 32768:
-            # big trees in HBM (C5): SURVEY.md 8(d) prices them by bytes -- per segment node bytes x nodes visited + 32 B
-            # (sphere + material record) x leaf spheres tested, per pixel one 16-byte sum -- against the HBM peak
+            # Big trees in HBM (C5).  SURVEY.md 8(d) prices them by algorithmic bytes -- per segment node bytes x nodes visited
+            # + 32 B x leaf spheres tested, per pixel one 16-byte sum -- but the L2 and the Infinity Cache serve nearly all of
+            # them (the counters see ~1/30 of that at the HBM interface) and the kernel is bound by VALU issue: the fraction
+            # on the line is the FP32 one, the HBM figure is the COUNTER traffic over the kernel time, the algorithmic bytes
+            # ride along as a side field.
             nb = float(st["node_bytes"])
             bytes_launch = segs / world * (nb * nvis / segs + 32.0 * stest / segs) + 16.0 * w * h
-            gbs = bytes_launch / (kernel_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                    "traffic": traffic, "traffic_run": traffic_run, "kernel": kernel_name + f" ({st['node_width']}-wide nodes of {st['node_bytes']} B)",
-                    "algorithmic_bytes_per_launch": int(bytes_launch), "node_visits_per_segment": round(nvis / segs, 2),
-                    "leaf_sphere_tests_per_segment": round(stest / segs, 2),
-                    "valu": {"achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "flop_per_sample": round(f_sample, 1)},
-                    "note": "SURVEY.md 8(d): C5 is priced by algorithmic bytes (node bytes x visits + 32 B x leaf tests per segment + 16 B per pixel) against the "
-                            "8 TB/s HBM peak; `traffic` is what the HBM counters saw for the same launch (the tree is served by the L2 and the Infinity Cache: "
-                            "the kernel is bound by VALU issue at ~40 % lane activity, see profiles/README.md)"}
+            roof["kernel"] = kernel_name + f" ({st['node_width']}-wide nodes of {st['node_bytes']} B)"
+            roof["algorithmic_bytes_per_launch"] = int(bytes_launch)
+            roof["node_visits_per_segment"] = round(nvis / segs, 2)
+            roof["hbm"] = None if traffic is None else {"achieved": round(traffic / (kernel_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                        "frac": round(traffic / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "source": "PMC traffic / live kernel time"}
+            roof["note"] = ("VALU-issue bound (profiles/README.md: lane activity ~0.55, L2 hit ~95 %): frac is the FP32 one (32 FLOP per child box tested "
+                            "+ 25|31 per leaf test, device counters); hbm = counter traffic, algorithmic_bytes_per_launch = SURVEY.md 8(d)'s byte figure "
+                            "(served by L2 / Infinity Cache, so it is no HBM roofline numerator)")
+        assert 0.0 <= roof["frac"] <= 1.0, roof
         name = "book-1 scene 1080p" if (args.scene, w, h) == (1, 1920, 1080) else f"scene {args.scene} {w}x{h}"
         out = {
             "metric": f"Msamples/s (whole node) {name}", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.spp_total > 0 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'init_test_scene_' + str(args.scene) if args.scene <= 3 else 'build-defined scene ' + str(args.scene)} ({'book-1 final, ' if args.scene == 1 else ''}{scene.n_spheres} spheres + {scene.n_planes} plane) "
-                                   f"{w}x{h}, depth {depth}, {S} spp per GPU = {S * world} spp total",
-                       "global_samples_per_step": samples_per_step, "parallelism": f"spp-split x{world} + RCCL all-reduce(sum) of the f32 accumulation buffer",
-                       "segments_per_sample": round(sbar, 4), "lane_utilisation": round(st["segments"] / (64.0 * max(1, st["wave_iterations"])), 4), "kernel_ms": round(kernel_ms, 3), "lib_kernel_ms_last": round(st["kernel_ms"], 3)},
+                                   f"{w}x{h}, depth {depth}, " + (f"{spp_all} spp total split over {world} GPU(s)" if args.spp_total > 0 else f"{S} spp per GPU = {spp_all} spp total"),
+                       "global_samples_per_step": samples_per_step, "parallelism": f"spp-split x{world} + RCCL all-reduce(sum) of the f32 accumulation buffer" + (f" [REHEARSAL: backend {os.environ['PT_BENCH_BACKEND']}, {n_visible} GPU(s) visible]" if use_dist and os.environ.get("PT_BENCH_BACKEND", "nccl") != "nccl" else ""),
+                       "segments_per_sample": round(sbar, 4), "lane_utilisation": round(st["segments"] / (64.0 * max(1, st["wave_iterations"])), 4), "kernel_ms": round(kernel_ms, 3), "lib_kernel_ms_last": round(st["kernel_ms"], 3),
+                       "step": "render -> " + ("all-reduce(sum, f32) -> " if use_dist else "") + "resolve + BGRA pack -> D2H of the packed image (pinned), all inside the timed region",
+                       "readback_ms": readback_ms},
             "roofline": roof,
         }
         if world == 1 and args.cpu_spp > 0:

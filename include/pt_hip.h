@@ -15,7 +15,9 @@
  * reference renderer where two reference runs agree to 50.6 dB (mean relative error 0.36 % vs 0.31 %).
  *
  * Conventions: every entry point returns an int status (0 = PT_OK, negative = pt_status); nothing aborts or
- * throws across the boundary (the reference is built /EHa- /GR-, src/build.bat:7).  The caller owns all host
+ * throws across the boundary (the reference is built /EHa- /GR-, src/build.bat:7): every entry point runs behind a
+ * catch-all barrier (a failed host allocation comes back as PT_ERR_NO_MEMORY, or NULL from the functions that return a
+ * handle), and a worker thread that cannot be started degrades to fewer threads, down to the calling one.  The caller owns all host
  * buffers before and after each call; the library copies on upload and owns its device memory inside pt_ctx.
  * A pt_ctx is bound to one GPU and is driven by one host thread at a time, with ONE render in flight at a time: the
  * unit cursor, statistics, partial images and timing events are per context, so a render enqueued on another stream
@@ -44,7 +46,9 @@ typedef enum pt_status {
     PT_ERR_HIP = -3,         /* a HIP call failed; pt_hip_last_error(ctx) has the text */
     PT_ERR_NO_SCENE = -4,    /* render / probe before pt_hip_upload_scene */
     PT_ERR_UNSUPPORTED = -5, /* e.g. more planes than the reference's 64 (src/render_world.h:88) */
-    PT_ERR_IO = -6           /* file could not be written */
+    PT_ERR_IO = -6,          /* file could not be written */
+    PT_ERR_NO_MEMORY = -7,   /* a host allocation failed inside the library (std::bad_alloc caught at the boundary) */
+    PT_ERR_INTERNAL = -8     /* any other C++ exception caught at the boundary; pt_hip_last_error(ctx) has its text */
 } pt_status;
 
 /* Material::Type, src/render_world.h:32-38 (same numeric values, same spelling of DIALECTRIC) */
@@ -106,6 +110,12 @@ typedef struct pt_params {
  * than the default; bit-equal to the reference's own query on the same tree (tests/golden q_t / q_obj), and converged
  * images then meet the reference renderer at its own noise floor (50.6 dB on the book-1 scene, not D1's 44 dB). */
 #define PT_FLAG_REFERENCE_QUERY 32u
+/* Progressive / resumable rendering (the reference's only analogue is its progress print,
+ * src/main.cpp:321-332): the frame's per-pixel sums are ADDED to what the output buffer already holds instead of replacing
+ * it, so a caller renders [0, 4096) in pieces into one resident buffer (zero it before the first piece).  pt_hip_render_device
+ * / _static and pt_node_render honour it; with PT_FLAG_REPRODUCIBLE the piece is folded in its fixed order first and added
+ * once, so piece k of a sequence leaves the same bits run to run. */
+#define PT_FLAG_ACCUMULATE 64u
 #define PT_REFERENCE_MAX_SPHERES 4192u /* World::objects[4192], src/render_world.h:85 */
 
 typedef struct pt_stats {
@@ -132,6 +142,19 @@ const char* pt_hip_last_error(pt_ctx* ctx);
 /* Replaces: World/Camera being handed to the workers through ThreadData (src/main.cpp:421-427) and
  * build_bvh_tree (src/main.cpp:402).  Copies the scene, lays it out for the device, builds the BVH if needed. */
 int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* scene);
+
+/* The same upload in two steps, for callers that put ONE scene on SEVERAL GPUs (pt_node_upload_scene does): the
+ * reference builds its tree once per process (src/main.cpp:402) and every worker reads it.
+ *   pt_scene_prepare    host only, touches no device: validates the scene, builds the BVH and every array the kernels
+ *                       read, in their device layout.  The result is immutable and may be committed to any number of
+ *                       contexts, from any thread.
+ *   pt_hip_commit_scene allocations + copies on the context's GPU; the prepared scene may be freed right after it.
+ *   pt_tree_build_count diagnostic: how many times this process has run the BVH builder (tests: one build, N commits). */
+typedef struct pt_prepared pt_prepared;
+int pt_scene_prepare(const pt_scene_desc* scene, pt_prepared** out);
+int pt_hip_commit_scene(pt_ctx* ctx, const pt_prepared* prepared);
+void pt_prepared_free(pt_prepared* prepared);
+uint64_t pt_tree_build_count(void);
 
 /* Replaces: build_bvh_tree (src/main.cpp:131-159, called at src/main.cpp:402) in the reference's own recipe, for
  * PT_FLAG_REFERENCE_QUERY: random axis per node from the main thread's std::mt19937 stream (src/utils.h:38-63), in-place
@@ -165,9 +188,12 @@ int pt_hip_render(pt_ctx* ctx, const pt_params* params, float* accum_rgba_host);
  * allocations do not guarantee. */
 int pt_hip_render_device(pt_ctx* ctx, const pt_params* params, float* accum_rgba_dev, void* stream);
 
-/* The same frame as pt_hip_render_device, bit for bit, through an entry point that ALLOCATES NOTHING: no hipMalloc,
- * hipFree or allocating library routine on any path.  No counterpart in the reference; it is for callers that cannot
- * allocate: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  The scratch that
+/* The same frame as pt_hip_render_device, bit for bit, through an entry point that ALLOCATES NO DEVICE MEMORY: no
+ * hipMalloc or hipFree on any path.  Host side: the first call for a new (kernel, workgroup shape) asks the runtime for
+ * that kernel's occupancy and remembers the answer in storage reserved at pt_hip_create; error texts are formatted into
+ * storage reserved there too; nothing else touches the heap.  Under stream capture the context's timing events are left
+ * out of the graph (pt_hip_last_stats then has nothing for that launch).  No counterpart in the reference; it is for
+ * callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  The scratch that
  * pt_hip_render_device keeps in (and grows inside) the context -- the unit cursor and per-wave statistics records the
  * persistent waves use, and the per-chunk partial images of a PT_FLAG_REPRODUCIBLE frame -- lives in a file-scope
  * `static __device__` array instead (1 MiB of cursor/statistics for up to 8192 resident waves + 32 MiB of partial
@@ -187,7 +213,9 @@ int pt_hip_render_device_static(pt_ctx* ctx, const pt_params* params, float* acc
  * ncclAllReduce(sum, f32) over xGMI, resolves on device 0 and copies back what was asked for: the f32 sums
  * (width*height*4, may be NULL) and / or the packed 0xAARRGGBB pixels (width*height, may be NULL).  Synchronous.  The
  * sample set is that of a one-GPU render of the same range (Philox is keyed by the global sample index); the sums
- * agree to float summation order.  RCCL is bound at run time: PT_ERR_UNSUPPORTED if n_gpus > 1 and it cannot be found. */
+ * agree to float summation order.  RCCL is bound at run time: PT_ERR_UNSUPPORTED if n_gpus > 1 and it cannot be found.
+ * pt_node_upload_scene builds the scene's tree ONCE on the host (pt_scene_prepare) and commits it to every GPU, as the
+ * reference builds once per process (src/main.cpp:402).  A call that fails drains every GPU's stream before it returns. */
 typedef struct pt_node pt_node;
 int pt_node_create(int n_gpus, pt_node** out);
 int pt_node_upload_scene(pt_node* node, const pt_scene_desc* scene);
@@ -196,6 +224,16 @@ void pt_node_destroy(pt_node* node);
 const char* pt_node_last_error(pt_node* node);
 int pt_node_gpu_count(const pt_node* node);
 pt_ctx* pt_node_ctx(pt_node* node, int gpu);   /* GPU g's context (statistics, reference tree, ...); owned by the node */
+/* Progressive / resumable rendering through the node (reference analogue: the per-block progress
+ * print, src/main.cpp:321-332).  pt_node_render with PT_FLAG_ACCUMULATE in params->flags (both host outputs NULL) renders
+ * its sample range like any other call -- split over the GPUs -- but ADDS each GPU's slice to that GPU's resident running
+ * sums and returns after enqueueing: no collective, no copy-back, so a C caller renders 4096 spp in pieces with no host-side
+ * sums.  pt_node_snapshot joins the running sums (one all-reduce into a second buffer: the per-GPU sums stay partial and
+ * keep growing), resolves by the samples rendered so far and copies back what is asked for (either may be NULL); *spp_out
+ * = samples per pixel in the snapshot.  All pieces of a sequence share one frame shape.  pt_node_reset forgets the
+ * resident sums (the next accumulating call starts from zero); so do pt_node_upload_scene and a plain pt_node_render. */
+int pt_node_snapshot(pt_node* node, float* accum_rgba_host, uint32_t* bgra_host, uint64_t* spp_out);
+int pt_node_reset(pt_node* node);
 /* The one-call form SURVEY.md 8(b) proposes: create + upload + render + destroy. */
 int pt_hip_render_node(const pt_scene_desc* scene, const pt_params* params, int n_gpus, float* accum_rgba_host);
 /* Host-only helper: the slice of the samples [spp_begin, spp_end) that part `part` of `n_parts` renders -- contiguous,

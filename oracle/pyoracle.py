@@ -313,11 +313,25 @@ class Ref:
     """The compiled reference.  Ref.available() is False on a box where it was neither built nor shipped."""
 
     @staticmethod
-    def available():
-        return os.path.exists(REF_SO)
+    def _path(flavour):
+        return REF_SO if flavour is None else REF_SO[:-3] + "_" + flavour + ".so"
 
-    def __init__(self, path=REF_SO):
-        self.lib = L = C.CDLL(path)
+    @staticmethod
+    def available(flavour=None):
+        """flavour None: the -O2 build every test uses.  "o3": the same sources at -O3 -march=x86-64-v3 (bench.py's courtesy
+        CPU figure); only offered on a CPU that has AVX2, FMA and BMI2 (the library would fault elsewhere)."""
+        if not os.path.exists(Ref._path(flavour)):
+            return False
+        if flavour == "o3":
+            try:
+                flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split()
+            except (OSError, StopIteration):
+                return False
+            return all(f in flags for f in ("avx2", "fma", "bmi2", "movbe", "abm"))
+        return True
+
+    def __init__(self, path=None, flavour=None):
+        self.lib = L = C.CDLL(path or Ref._path(flavour))
         L.ref_scene_new.restype = C.c_void_p
         L.ref_scene_builtin.restype = C.c_void_p
         L.ref_reflectance.restype = C.c_double

@@ -15,20 +15,22 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
 
 PT_OK = 0
 PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_UNSUPPORTED, PT_ERR_IO = -1, -2, -3, -4, -5, -6
+PT_ERR_NO_MEMORY, PT_ERR_INTERNAL = -7, -8
 MAT_NONE, MAT_DIFFUSE, MAT_METAL, MAT_DIALECTRIC = 0, 1, 2, 3
 FLAG_STRICT_SEARCH, FLAG_FORCE_BVH, FLAG_FORCE_LDS, FLAG_BRUTE_FORCE, FLAG_REPRODUCIBLE, FLAG_REFERENCE_QUERY = 1, 2, 4, 8, 16, 32
+FLAG_ACCUMULATE = 64
 REFERENCE_MAX_SPHERES = 4192
 PRIM_MISS = -(2 ** 31)
 
 # Every symbol include/pt_hip.h declares (tests/test_abi.py checks the library exports exactly these).
 EXPORTS = (
     "pt_hip_device_count", "pt_hip_create", "pt_hip_destroy", "pt_hip_strerror", "pt_hip_last_error",
-    "pt_hip_upload_scene", "pt_hip_build_reference_tree", "pt_reference_bvh", "pt_hip_render", "pt_hip_render_device", "pt_hip_render_device_static", "pt_hip_last_stats", "pt_hip_debug_counters", "pt_chunk_schedule", "pt_bvh_selfcheck", "pt_hip_resolve_device",
+    "pt_hip_upload_scene", "pt_scene_prepare", "pt_hip_commit_scene", "pt_prepared_free", "pt_tree_build_count", "pt_hip_build_reference_tree", "pt_reference_bvh", "pt_hip_render", "pt_hip_render_device", "pt_hip_render_device_static", "pt_hip_last_stats", "pt_hip_debug_counters", "pt_chunk_schedule", "pt_bvh_selfcheck", "pt_hip_resolve_device",
     "pt_resolve", "pt_pack_bgra", "pt_bmp_write", "pt_bmp_write_bgra", "pt_bmp_header",
     "pt_scene_builtin", "pt_scene_get_desc", "pt_scene_free", "pt_scene_save", "pt_scene_load",
     "pt_hip_probe_primitives", "pt_hip_probe_hits", "pt_hip_probe_get_rays", "pt_hip_probe_scatter", "pt_hip_probe_paths",
     "pt_hip_probe_samples", "pt_hip_probe_philox",
-    "pt_node_create", "pt_node_upload_scene", "pt_node_render", "pt_node_destroy", "pt_node_last_error", "pt_node_gpu_count", "pt_node_ctx",
+    "pt_node_create", "pt_node_upload_scene", "pt_node_render", "pt_node_destroy", "pt_node_last_error", "pt_node_gpu_count", "pt_node_ctx", "pt_node_snapshot", "pt_node_reset",
     "pt_hip_render_node", "pt_spp_slice",
 )
 
@@ -93,6 +95,11 @@ def load_library(path=LIB_PATH):
     L.pt_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.pt_hip_destroy.argtypes = [C.c_void_p]
     L.pt_hip_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+    L.pt_scene_prepare.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+    L.pt_hip_commit_scene.argtypes = [C.c_void_p, C.c_void_p]
+    L.pt_prepared_free.argtypes = [C.c_void_p]
+    L.pt_prepared_free.restype = None
+    L.pt_tree_build_count.restype = C.c_uint64
     L.pt_hip_build_reference_tree.argtypes = [C.c_void_p, C.c_uint32]
     L.pt_reference_bvh.argtypes = [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
     L.pt_reference_bvh.restype = C.c_uint32
@@ -109,6 +116,8 @@ def load_library(path=LIB_PATH):
     L.pt_node_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.pt_node_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
     L.pt_node_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]
+    L.pt_node_snapshot.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.pt_node_reset.argtypes = [C.c_void_p]
     L.pt_node_destroy.argtypes = [C.c_void_p]
     L.pt_node_last_error.argtypes = [C.c_void_p]
     L.pt_node_last_error.restype = C.c_char_p
@@ -233,10 +242,48 @@ class Scene:
             raise PtError(PT_ERR_UNSUPPORTED if n > REFERENCE_MAX_SPHERES else PT_ERR_INVALID, "pt_reference_bvh")
         return boxes, links, order, int(depth.value)
 
+    def prepare(self):
+        """Host-only half of an upload (pt_scene_prepare): -> Prepared, to be committed to any number of Renderers."""
+        return Prepared(self)
+
     def save(self, path):
         st = load_library().pt_scene_save(C.byref(self.desc), os.fsencode(path))
         if st != PT_OK:
             raise PtError(st, f"pt_scene_save({path})")
+
+
+class Prepared:
+    """pt_prepared: a scene laid out for the device, tree built, still on the host."""
+
+    def __init__(self, scene: Scene):
+        self.L = load_library()
+        h = C.c_void_p()
+        st = self.L.pt_scene_prepare(C.byref(scene.desc), C.byref(h))
+        if st != PT_OK:
+            raise PtError(st, "pt_scene_prepare")
+        self.h, self.scene = h, scene
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pt_prepared_free(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def tree_build_count():
+    """Runs of the BVH builder in this process so far (pt_tree_build_count)."""
+    return int(load_library().pt_tree_build_count())
 
 
 def device_count():
@@ -274,11 +321,15 @@ class Renderer:
 
     def _check(self, st, what):
         if st != PT_OK:
-            raise PtError(st, what, self.L.pt_hip_last_error(self.h).decode() if st in (PT_ERR_HIP, PT_ERR_UNSUPPORTED) else "")
+            raise PtError(st, what, self.L.pt_hip_last_error(self.h).decode() if st in (PT_ERR_HIP, PT_ERR_UNSUPPORTED, PT_ERR_NO_MEMORY, PT_ERR_INTERNAL) else "")
 
     def upload(self, scene: Scene):
         self._check(self.L.pt_hip_upload_scene(self.h, C.byref(scene.desc)), "pt_hip_upload_scene")
         self.scene = scene
+
+    def commit(self, prepared: Prepared):
+        self._check(self.L.pt_hip_commit_scene(self.h, prepared.h), "pt_hip_commit_scene")
+        self.scene = prepared.scene
 
     def build_reference_tree(self, rng_skip=0):
         """The reference-topology tree PT_FLAG_REFERENCE_QUERY traverses (rng_skip: draws taken from the main thread's
@@ -413,6 +464,22 @@ class Node:
         p = Params(width, height, spp_begin, spp_end, max_depth, flags, seed)
         self._check(self.L.pt_node_render(self.h, C.byref(p), _ptr(out), _ptr(bgra)), "pt_node_render")
         return (out, bgra) if want_bgra else out
+
+    def accumulate(self, width, height, spp_begin, spp_end, max_depth, seed=0, flags=0):
+        """One piece of a progressive render: added to the node's resident sums, nothing read back (asynchronous)."""
+        p = Params(width, height, spp_begin, spp_end, max_depth, flags | FLAG_ACCUMULATE, seed)
+        self._check(self.L.pt_node_render(self.h, C.byref(p), None, None), "pt_node_render(PT_FLAG_ACCUMULATE)")
+
+    def snapshot(self, width, height, want_sums=True, want_bgra=True):
+        """-> (sums or None, bgra or None, spp so far) of the resident running sums (pt_node_snapshot)."""
+        out = np.empty((height, width, 4), np.float32) if want_sums else None
+        bgra = np.empty((height, width), np.uint32) if want_bgra else None
+        spp = C.c_uint64(0)
+        self._check(self.L.pt_node_snapshot(self.h, _ptr(out), _ptr(bgra), C.byref(spp)), "pt_node_snapshot")
+        return out, bgra, int(spp.value)
+
+    def reset(self):
+        self._check(self.L.pt_node_reset(self.h), "pt_node_reset")
 
     def stats(self, gpu=0):
         s = Stats()

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/pt_hip.h"
+#include "pt_guard.h"
 
 namespace pth {
 
@@ -102,10 +103,7 @@ inline void build_bvh(const pt_scene_desc* d, BvhData* out)
     struct Task { uint32_t begin, end, parent, side, depth; }; // parent = node index in the SAME array (or kNoParent), side 0/1
     constexpr uint32_t kNoParent = 0xFFFFFFFFu;
     constexpr int NB = 16;
-    unsigned nthreads = std::thread::hardware_concurrency();
-    if (nthreads == 0) nthreads = 1;
-    if (nthreads > 16) nthreads = 16;
-    if (const char* e = getenv("PT_BUILD_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) nthreads = (unsigned)v; }
+    unsigned nthreads = ptg::host_threads(16); // (affinity mask and cgroup quota respected; a thread that cannot start runs inline)
     if (n < 65536) nthreads = 1;
     out->nodes.clear();
     out->depth = 0;
@@ -119,10 +117,8 @@ inline void build_bvh(const pt_scene_desc* d, BvhData* out)
     // run f(slice_begin, slice_end, slice_index) over [b, e) on `workers` threads (1 = inline)
     auto parallel_slices = [&](uint32_t b, uint32_t e, unsigned workers, const std::function<void(uint32_t, uint32_t, unsigned)>& f) {
         if (workers <= 1 || e - b < 32768) { f(b, e, 0); return 1u; }
-        std::vector<std::thread> th;
         const uint64_t len = e - b;
-        for (unsigned w = 0; w < workers; ++w) th.emplace_back(f, b + (uint32_t)(len * w / workers), b + (uint32_t)(len * (w + 1) / workers), w);
-        for (auto& t : th) t.join();
+        ptg::run_workers(workers, [&](unsigned w) { f(b + (uint32_t)(len * w / workers), b + (uint32_t)(len * (w + 1) / workers), w); });
         return workers;
     };
     struct Bins { Aabb bb[3][NB]; uint32_t bc[3][NB]; float clo[3], chi[3]; };
@@ -225,9 +221,7 @@ inline void build_bvh(const pt_scene_desc* d, BvhData* out)
         if (nthreads > 1)
         {
             std::atomic<size_t> next{0};
-            std::vector<std::thread> th;
-            for (unsigned w = 0; w < nthreads; ++w) th.emplace_back([&]() { for (size_t j; (j = next.fetch_add(1)) < frontier.size();) build_sub(j); });
-            for (auto& t : th) t.join();
+            ptg::run_workers(nthreads, [&](unsigned) { for (size_t j; (j = next.fetch_add(1)) < frontier.size();) build_sub(j); });
         }
         else
             for (size_t j = 0; j < frontier.size(); ++j) build_sub(j);
@@ -339,7 +333,7 @@ inline void widen_nodes(const BvhData& in, const pt_scene_desc* d, bool single, 
     out->nodes.clear(); out->n_nodes = 0; out->depth = 0; out->root_ref = in.root_ref;
     for (int k = 0; k < 3; ++k) { grid->org[k] = 0.0f; grid->step[k] = 1.0f; }
     if (in.n_spheres == 0) return;
-    struct Child { Aabb box; uint32_t ref; };
+    struct Child { Aabb box; uint32_t ref; bool made = false; }; // made: ref already names a WIDE node (an over-full leaf's remainder)
     // the padded, swept box of one sphere slot, as build_bvh forms it (same pad: the leaf test is the exact one)
     float extent = 1.0f;
     for (int k = 0; k < 3; ++k) if (fabsf(d->camera[k]) > extent) extent = fabsf(d->camera[k]);
@@ -366,7 +360,7 @@ inline void widen_nodes(const BvhData& in, const pt_scene_desc* d, bool single, 
     };
     auto bin_child = [&](uint32_t node, int side) {
         const float* nd = in.nodes.data() + 16 * (size_t)node;
-        Child c;
+        Child c{};
         for (int k = 0; k < 3; ++k) { c.box.lo[k] = nd[6 * side + k]; c.box.hi[k] = nd[6 * side + 3 + k]; }
         c.ref = f2u(nd[12 + side]);
         return c;
@@ -380,7 +374,7 @@ inline void widen_nodes(const BvhData& in, const pt_scene_desc* d, bool single, 
     struct Job { std::vector<Child> kids; uint32_t self, level; };
     std::vector<Job> todo;
     auto new_node = [&]() { wide.push_back(Wide{}); return (uint32_t)wide.size() - 1; };
-    auto leaf_kids = [&](uint32_t ref) { std::vector<Child> k; for (uint32_t i = 0; i < leaf_count(ref); ++i) k.push_back(Child{slot_box(leaf_first(ref) + i), single_ref(leaf_first(ref) + i)}); return k; };
+    auto leaf_kids = [&](uint32_t ref) { std::vector<Child> k; for (uint32_t i = 0; i < leaf_count(ref); ++i) k.push_back(Child{slot_box(leaf_first(ref) + i), single_ref(leaf_first(ref) + i), false}); return k; };
     if (in.n_nodes == 0)
     {
         // the whole scene is one leaf of the binary tree
@@ -398,13 +392,24 @@ inline void widen_nodes(const BvhData& in, const pt_scene_desc* d, bool single, 
         Job job = std::move(todo.back()); todo.pop_back();
         if (job.level > out->depth) out->depth = job.level;
         std::vector<Child>& kids = job.kids;
+        // a leaf of more than four spheres (PT_LEAF_MAX 5..8): three of them here, the rest behind a node one level down
+        if (kids.size() > 4)
+        {
+            std::vector<Child> rest(kids.begin() + 3, kids.end());
+            kids.resize(3);
+            Child c{}; aabb_reset(c.box);
+            for (const Child& r : rest) aabb_grow(c.box, r.box);
+            c.ref = new_node(); c.made = true;
+            todo.push_back(Job{std::move(rest), c.ref, job.level + 1});
+            kids.push_back(c);
+        }
         // pull grandchildren up, largest box first, while there is room
         for (;;)
         {
             if (kids.size() >= 4) break;
             int pick = -1; float area = -1.0f;
             for (size_t j = 0; j < kids.size(); ++j)
-                if (!(kids[j].ref & kLeafFlag) && aabb_area(kids[j].box) > area) { area = aabb_area(kids[j].box); pick = (int)j; }
+                if (!(kids[j].ref & kLeafFlag) && !kids[j].made && aabb_area(kids[j].box) > area) { area = aabb_area(kids[j].box); pick = (int)j; }
             if (pick < 0) break;
             const uint32_t node = kids[(size_t)pick].ref;
             kids[(size_t)pick] = bin_child(node, 0);
@@ -426,6 +431,7 @@ inline void widen_nodes(const BvhData& in, const pt_scene_desc* d, bool single, 
         for (uint32_t j = 0; j < w.n; ++j)
         {
             w.c[j] = kids[j];
+            if (kids[j].made) continue;                           // (its node and job exist already)
             if (!(kids[j].ref & kLeafFlag))                       // an inner node of the binary tree: a wide node of its own
             {
                 const uint32_t self = new_node();
@@ -483,17 +489,9 @@ inline void widen_nodes(const BvhData& in, const pt_scene_desc* d, bool single, 
         }
     };
     // (ten million cell computations at 10^6 spheres: sliced over the builder's worker threads)
-    unsigned workers = std::thread::hardware_concurrency();
-    if (workers == 0) workers = 1;
-    if (workers > 16) workers = 16;
-    if (const char* e = getenv("PT_BUILD_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) workers = (unsigned)v; }
+    const unsigned workers = ptg::host_threads(16);
     if (wide.size() < 65536 || workers == 1) quantise(0, wide.size());
-    else
-    {
-        std::vector<std::thread> th;
-        for (unsigned w = 0; w < workers; ++w) th.emplace_back(quantise, wide.size() * w / workers, wide.size() * (w + 1) / workers);
-        for (auto& t : th) t.join();
-    }
+    else ptg::run_workers(workers, [&](unsigned w) { quantise(wide.size() * w / workers, wide.size() * (w + 1) / workers); });
 }
 
 } // namespace pth

@@ -10,6 +10,8 @@
 //                              the calling thread, down to n = 1 = a serial loop.
 // Host-only.
 #pragma once
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <exception>
 #include <new>
@@ -83,6 +85,29 @@ template <class F> inline unsigned run_workers(unsigned n, F&& fn)
     for (std::thread& t : th) t.join();
     for (const std::exception_ptr& e : failed) if (e) std::rethrow_exception(e);
     return started + 1;
+}
+
+// Worker threads a host-side pass may use: the CPUs this process may run on (its affinity mask), further capped by the
+// cgroup CPU quota when one is set (a GPU box hands one GPU's job a share of the machine: threads beyond it are only
+// throttled) and by `cap`; PT_BUILD_THREADS overrides (tests / tuning).
+inline unsigned host_threads(unsigned cap)
+{
+    if (const char* e = getenv("PT_BUILD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) return (unsigned)v; }
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && (n == 0 || (unsigned)c < n)) n = (unsigned)c; }
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r"))
+    {
+        char q[32] = {0}; double period = 0;
+        if (fscanf(f, "%31s %lf", q, &period) == 2 && q[0] != 'm' && period > 0)
+        {
+            const unsigned quota = (unsigned)(atof(q) / period + 0.5);
+            if (quota >= 1 && quota < n) n = quota;
+        }
+        fclose(f);
+    }
+    if (n == 0) n = 1;
+    return n > cap ? cap : n;
 }
 
 } // namespace ptg

@@ -18,11 +18,13 @@
 #include <string.h>
 #include <math.h>
 #include <cmath>
+#include <atomic>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/pt_hip.h"
+#include "pt_guard.h"
 #include "pt_device.h"
 #include "pt_host.h"
 #include "pt_bvh.h"
@@ -551,7 +553,8 @@ __global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ sum,
 }
 
 // Sum of the per-chunk partial images in chunk order (a fixed order: the frame does not depend on which wave ran which unit).
-__global__ void __launch_bounds__(256) k_fold_chunks(const float4* __restrict__ partial, uint32_t nchunks, uint32_t n, float4* __restrict__ out)
+// add: the frame's sums join what `out` holds (PT_FLAG_ACCUMULATE) -- the frame is folded first, then added once.
+__global__ void __launch_bounds__(256) k_fold_chunks(const float4* __restrict__ partial, uint32_t nchunks, uint32_t n, float4* __restrict__ out, uint32_t add)
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     {
@@ -561,6 +564,7 @@ __global__ void __launch_bounds__(256) k_fold_chunks(const float4* __restrict__ 
             const float4 w = partial[(size_t)c * n + i];
             v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         }
+        if (add) { const float4 o = out[i]; v.x = o.x + v.x; v.y = o.y + v.y; v.z = o.z + v.z; v.w = o.w + v.w; }
         out[i] = v;
     }
 }
@@ -571,8 +575,6 @@ struct pt_ctx
     int device = -1;
     std::string err;
     bool has_scene = false, moving = false, lds_ok = false, bvh_lds_ok = false;
-    // LDS mode: the whole scene as one blob; BVH mode: planes-only blob + tree and payload in HBM
-    pth::Blob blob, blob_planes;
     DeviceCamera cam{};          // folded camera of the uploaded scene (probe_get_rays; the kernels read the copy in the scene image)
     float4* blob_dev = nullptr; float4* blob_planes_dev = nullptr; float4* blob_bvh_dev = nullptr; // brute-force image, planes only, planes + tree
     float4* nodes_dev = nullptr; float4* sph_dev = nullptr; float4* vel_dev = nullptr; float4* mat_dev = nullptr;
@@ -600,6 +602,23 @@ struct pt_ctx
     std::vector<Occ> occ;   // answers of the occupancy query (render_occupancy)
 };
 
+// A scene laid out for the device, still on the host (pt_scene_prepare): every array pt_hip_commit_scene copies, and the
+// kernel arguments with their device pointers null.  Immutable once built: any number of contexts may commit from it.
+struct pt_prepared
+{
+    std::string err;
+    DeviceCamera cam{};
+    bool moving = false, lds_ok = false, bvh_lds_ok = false, bvh_q = false, bvh_wide = false, mat_in_lds = false;
+    pth::Blob blob, blob_planes;           // brute-force image of the whole scene (if it fits LDS); planes + camera only
+    std::vector<float> nodes_f;            // the tree read from HBM: 64-byte float nodes ...
+    std::vector<uint32_t> nodes_u;         // ... or grid nodes (32-byte 2-wide / 64-byte 4-wide)
+    std::vector<float> sph, vel, mat;      // sphere payload in leaf order
+    std::vector<float> bvh_lds_img;        // planes + tree + spheres staged in LDS by the MODE_BVH_LDS kernels
+    SceneArgs sc_lds{}, sc_bvh{}, sc_bvh_lds{};
+    uint32_t bvh_nodes = 0, bvh_depth = 0;
+    pt_scene_desc desc{}; std::vector<float> h_pos_r, h_vel; std::vector<uint32_t> slot_of_sphere;
+};
+
 extern "C" int pt_hip_build_reference_tree(pt_ctx* ctx, uint32_t rng_skip);
 
 namespace {
@@ -612,6 +631,10 @@ namespace {
             return PT_ERR_HIP;                                                                                  \
         }                                                                                                       \
     } while (0)
+
+// Every extern "C" body runs between these two (pt_guard.h): no C++ exception leaves the library.
+#define PT_ENTER(errp, name) return ptg::guard_status((errp), name, [&]() -> int {
+#define PT_LEAVE });
 
 struct Bind // make the context's device current for the duration of a call
 {
@@ -775,6 +798,176 @@ void fill_scene_args(SceneArgs* sc, const pth::Blob& b, const float4* dev, const
     if (const char* e = getenv("PT_REFILL_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) sc->refill_min = (uint32_t)v; } // tuning experiments only
 }
 
+
+std::atomic<uint64_t> g_tree_builds{0};    // runs of pth::build_bvh in this process (pt_tree_build_count: "one build, N commits")
+
+// Host half of a scene upload: every array the kernels will read, laid out, and the kernel arguments with their device
+// pointers still null.  Touches no device.
+int prepare_scene(const pt_scene_desc* d, pt_prepared* P)
+{
+    int st = pth::validate_desc(d);
+    if (st != PT_OK) return st;
+    pth::make_device_camera(d->camera, &P->cam);
+    // (1) LDS image of the whole scene, if it can fit beside the accumulators of a 4-wave workgroup
+    const size_t roughBytes = (size_t)d->n_spheres * (16 + 16 + 32 + 2) + (size_t)d->n_planes * 48 + 4096;
+    P->lds_ok = false;
+    if (roughBytes <= kMaxLdsBytes)
+    {
+        pth::build_blob(d, &P->blob);
+        P->lds_ok = P->blob.f4.size() * 16 + kWavesPerBlock * kAccBytesPerWave <= kMaxLdsBytes;
+    }
+    if (P->lds_ok)
+    {
+        fill_scene_args(&P->sc_lds, P->blob, nullptr, d, d->n_planes);
+        P->sc_lds.bvh = BvhView{};
+        P->moving = P->blob.moving;
+    }
+    else
+        P->blob = pth::Blob{};
+    // (2) BVH in HBM (always built: it is what PT_FLAG_FORCE_BVH and every scene beyond LDS use) + planes-only LDS image
+    pth::BvhData bv;
+    pth::build_bvh(d, &bv);
+    g_tree_builds.fetch_add(1);
+    pt_scene_desc planesOnly = *d;
+    planesOnly.n_spheres = 0;
+    pth::build_blob(&planesOnly, &P->blob_planes);
+    // Big trees are read from HBM as 32-byte grid nodes (half the loads per step: the L1 is what binds that kernel);
+    // small ones, resident in L1/L2 and bound by instruction issue, keep the 64-byte float nodes.
+    // ... and from kGridNodeMinSpheres up as 64-byte 4-wide grid nodes over single spheres (MODE_BVH_Q4): half the
+    // dependent fetches per ray.  PT_GRID_NODES (tests / tuning): 0 float nodes, 1 32-byte 2-wide, 2 4-wide over
+    // the binary tree's leaves, 3 4-wide over single spheres (the default for big trees).
+    int gridKind = bv.n_spheres >= kGridNodeMinSpheres ? 3 : 0;
+    if (const char* e = getenv("PT_GRID_NODES")) gridKind = atoi(e);
+    if (gridKind < 0 || gridKind > 3) gridKind = 0;
+    if (bv.n_spheres == 0) gridKind = 0;
+    P->bvh_q = gridKind == 1 && bv.n_nodes != 0;
+    P->bvh_wide = false;
+    pth::NodeGrid grid{};
+    pth::WideData wd;
+    if (gridKind >= 2)
+    {
+        pth::widen_nodes(bv, d, gridKind == 3, &grid, &wd);
+        // (a tree too deep for the stack's LDS + scratch levels keeps the 2-wide grid nodes)
+        if (wd.n_nodes != 0 && 3u * wd.depth + 1u <= kWideStackLds + kOvfEntries) P->bvh_wide = true;
+        else P->bvh_q = bv.n_nodes != 0;
+    }
+    if (P->bvh_wide) P->nodes_u.swap(wd.nodes);
+    else if (P->bvh_q) pth::quantise_nodes(bv, &grid, &P->nodes_u);
+    fill_scene_args(&P->sc_bvh, P->blob_planes, nullptr, d, d->n_planes);
+    P->sc_bvh.bvh = BvhView{nullptr, nullptr, nullptr, nullptr, P->bvh_wide ? wd.root_ref : bv.root_ref, bv.n_spheres,
+                            {grid.org[0], grid.org[1], grid.org[2]}, {grid.step[0], grid.step[1], grid.step[2]}};
+    P->sc_bvh.stack_entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1; // the sentinel + at most one pushed sibling per inner node of a root-to-leaf path (bv.depth of them)
+    if (P->bvh_wide)
+    {
+        // up to three pushed siblings per level; the first kWideStackLds levels in LDS, the rest in scratch (pt_device.h)
+        uint32_t capLds = kWideStackLds;
+        if (const char* e = getenv("PT_WIDE_STACK")) { int v = atoi(e); if (v >= 2 && v <= 255) capLds = (uint32_t)v; } // tuning experiments only
+        const uint32_t need = 3u * wd.depth + 1u;
+        P->sc_bvh.stack_entries = need < capLds ? (need < 4 ? 4 : need) : capLds;
+        if (need > P->sc_bvh.stack_entries + kOvfEntries) { P->err = "wide BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
+    }
+    P->sc_bvh.leaf_batch = kLeafBatch;
+    int exitEnv = -1;
+    if (const char* e = getenv("PT_EXIT_LANES")) { int v = atoi(e); if (v >= 0 && v <= 64) exitEnv = v; } // tuning experiments only
+    const bool resumable = bv.n_spheres > kResumeMinSpheres;
+
+    int exitMul = -1;
+    if (const char* e = getenv("PT_EXIT_MUL")) { int v = atoi(e); if (v >= 1 && v <= 255) exitMul = v; } // tuning experiments only
+    P->sc_bvh.exit_lanes = !resumable ? 0u : pack_exit_rule(exitEnv >= 0 ? (uint32_t)exitEnv : P->bvh_wide ? kExitLanesWide : kExitLanesHbm,
+                                                           exitMul > 0 ? (uint32_t)exitMul : P->bvh_wide ? kExitMulWide : kExitMul);
+    if (P->bvh_wide) P->sc_bvh.leaf_batch = kLeafBatchWide;
+    const uint32_t refillLds = P->sc_bvh.refill_min; // (fill_scene_args: the default, or PT_REFILL_MIN)
+    if (!getenv("PT_REFILL_MIN")) P->sc_bvh.refill_min = P->bvh_wide ? kRefillMinWide : kRefillMinHbm;
+    const uint32_t carryLds = P->sc_bvh.carry_max; // (fill_scene_args: the default, or PT_CARRY_MAX)
+    if (!getenv("PT_CARRY_MAX")) P->sc_bvh.carry_max = P->bvh_wide ? kCarryMaxWide : kCarryMaxHbm;
+    if (const char* e = getenv("PT_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) P->sc_bvh.leaf_batch = (uint32_t)v; } // tuning experiments only
+    P->bvh_nodes = bv.n_nodes; P->bvh_depth = bv.depth;
+    P->moving = bv.moving;
+    // what pt_hip_build_reference_tree needs later: the spheres as the caller numbered them, and where each one sits now
+    P->desc = *d;
+    P->h_pos_r.assign(d->sphere_pos_r, d->sphere_pos_r + 4 * (size_t)d->n_spheres);
+    if (d->sphere_vel) P->h_vel.assign(d->sphere_vel, d->sphere_vel + 3 * (size_t)d->n_spheres); else P->h_vel.clear();
+    P->desc.sphere_pos_r = nullptr; P->desc.sphere_vel = nullptr; // (commit points them at the context's own copies)
+    P->desc.sphere_mat_type = nullptr; P->desc.sphere_mat_rgba = nullptr; P->desc.sphere_mat_param = nullptr;
+    P->desc.plane_n_d = nullptr; P->desc.plane_mat_type = nullptr; P->desc.plane_mat_rgba = nullptr; P->desc.plane_mat_param = nullptr;
+    P->slot_of_sphere.assign(d->n_spheres, 0u);
+    for (uint32_t slot = 0; slot < bv.n_spheres; ++slot) P->slot_of_sphere[pth::f2u(bv.mat[8 * (size_t)slot + 3])] = slot;
+    if (bv.depth + 1 > kBvhStack) { P->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
+    // (3) the same tree staged in LDS behind the planes, when planes + tree + payload + 4 waves' stacks fit
+    const uint32_t entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1; // (the binary tree's: sc_bvh may hold the 4-wide tree's figure)
+    // Materials are read once per hit, the tree and the spheres at every step: only the latter are worth LDS, and
+    // the smaller image lets more waves share a CU.
+    P->mat_in_lds = getenv("PT_MAT_LDS") != nullptr; // tuning experiments only
+    const size_t f4s = P->blob_planes.f4.size() + (bv.nodes.size() + bv.sph.size() + bv.vel.size() + (P->mat_in_lds ? bv.mat.size() : 0)) / 4;
+    P->bvh_lds_ok = f4s * 16 + kWavesPerBlock * (kAccBytesPerWave + (size_t)entries * 256) <= kMaxLdsBytes;
+    if (P->bvh_lds_ok)
+    {
+        std::vector<float>& img = P->bvh_lds_img;
+        img.resize(P->blob_planes.f4.size() * 4);
+        if (!img.empty()) memcpy(img.data(), P->blob_planes.f4.data(), img.size() * 4);
+        uint32_t off[4];
+        const std::vector<float>* parts[4] = {&bv.nodes, &bv.sph, &bv.vel, &bv.mat};
+        for (int k = 0; k < 4; ++k)
+        {
+            if (k == 3 && !P->mat_in_lds) { off[k] = 0xFFFFFFFFu; continue; }
+            off[k] = (uint32_t)(img.size() / 4); img.insert(img.end(), parts[k]->begin(), parts[k]->end());
+        }
+        P->sc_bvh_lds = P->sc_bvh;
+        P->sc_bvh_lds.exit_lanes = !resumable ? 0u : pack_exit_rule(exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanes, exitMul > 0 ? (uint32_t)exitMul : kExitMul);
+        P->sc_bvh_lds.refill_min = refillLds;
+        if (!getenv("PT_LEAF_BATCH")) P->sc_bvh_lds.leaf_batch = kLeafBatchLds;
+        P->sc_bvh_lds.carry_max = carryLds;
+        P->sc_bvh_lds.blob = nullptr; P->sc_bvh_lds.blob_f4 = (uint32_t)(img.size() / 4);
+        for (int k = 0; k < 4; ++k) P->sc_bvh_lds.bvh_off[k] = off[k];
+        P->sc_bvh_lds.bvh = BvhView{nullptr, nullptr, nullptr, nullptr, bv.root_ref, bv.n_spheres, {0, 0, 0}, {1, 1, 1}};
+        P->sc_bvh_lds.stack_entries = entries;
+    }
+    if (!P->bvh_wide && !P->bvh_q) P->nodes_f.swap(bv.nodes);
+    P->sph.swap(bv.sph); P->vel.swap(bv.vel); P->mat.swap(bv.mat);
+    return PT_OK;
+}
+
+// Device half: allocations and copies on the context's GPU, then the kernel arguments get their pointers.
+int commit_scene(pt_ctx* ctx, const pt_prepared& P)
+{
+    Bind b(ctx);
+    if (!b.ok) return PT_ERR_NO_DEVICE;
+    free_scene(ctx);
+    ctx->err.clear();
+    ctx->cam = P.cam;
+    ctx->lds_ok = P.lds_ok; ctx->bvh_lds_ok = P.bvh_lds_ok; ctx->bvh_q = P.bvh_q; ctx->bvh_wide = P.bvh_wide; ctx->moving = P.moving;
+    ctx->bvh_nodes = P.bvh_nodes; ctx->bvh_depth = P.bvh_depth;
+    // host-side copies for pt_hip_build_reference_tree (the prepared scene may be freed right after the commit)
+    ctx->h_pos_r = P.h_pos_r; ctx->h_vel = P.h_vel; ctx->slot_of_sphere = P.slot_of_sphere;
+    ctx->desc = P.desc;
+    ctx->desc.sphere_pos_r = ctx->h_pos_r.data(); ctx->desc.sphere_vel = ctx->h_vel.empty() ? nullptr : ctx->h_vel.data();
+    int st;
+    if (P.lds_ok)
+    {
+        st = upload_f4(ctx, P.blob.f4.data(), P.blob.f4.size() * 16, &ctx->blob_dev); if (st != PT_OK) return st;
+        ctx->sc_lds = P.sc_lds; ctx->sc_lds.blob = ctx->blob_dev;
+    }
+    st = upload_f4(ctx, P.blob_planes.f4.data(), P.blob_planes.f4.size() * 16, &ctx->blob_planes_dev); if (st != PT_OK) return st;
+    if (P.bvh_wide || P.bvh_q) st = upload_f4(ctx, P.nodes_u.data(), P.nodes_u.size() * 4, &ctx->nodes_dev);
+    else st = upload_f4(ctx, P.nodes_f.data(), P.nodes_f.size() * 4, &ctx->nodes_dev);
+    if (st != PT_OK) return st;
+    st = upload_f4(ctx, P.sph.data(), P.sph.size() * 4, &ctx->sph_dev); if (st != PT_OK) return st;
+    st = upload_f4(ctx, P.vel.data(), P.vel.size() * 4, &ctx->vel_dev); if (st != PT_OK) return st;
+    st = upload_f4(ctx, P.mat.data(), P.mat.size() * 4, &ctx->mat_dev); if (st != PT_OK) return st;
+    ctx->sc_bvh = P.sc_bvh;
+    ctx->sc_bvh.blob = ctx->blob_planes_dev;
+    ctx->sc_bvh.bvh.nodes = ctx->nodes_dev; ctx->sc_bvh.bvh.sph = ctx->sph_dev; ctx->sc_bvh.bvh.vel = ctx->vel_dev; ctx->sc_bvh.bvh.mat = ctx->mat_dev;
+    if (P.bvh_lds_ok)
+    {
+        st = upload_f4(ctx, P.bvh_lds_img.data(), P.bvh_lds_img.size() * 4, &ctx->blob_bvh_dev); if (st != PT_OK) return st;
+        ctx->sc_bvh_lds = P.sc_bvh_lds;
+        ctx->sc_bvh_lds.blob = ctx->blob_bvh_dev;
+        ctx->sc_bvh_lds.bvh.mat = P.mat_in_lds ? nullptr : ctx->mat_dev;
+    }
+    ctx->has_scene = true;
+    return PT_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -797,6 +990,8 @@ const char* pt_hip_strerror(int status)
     case PT_ERR_NO_SCENE: return "no scene uploaded";
     case PT_ERR_UNSUPPORTED: return "unsupported scene or flag combination";
     case PT_ERR_IO: return "I/O error";
+    case PT_ERR_NO_MEMORY: return "out of host memory";
+    case PT_ERR_INTERNAL: return "internal error (exception caught at the library boundary)";
     default: return "unknown status";
     }
 }
@@ -805,6 +1000,7 @@ const char* pt_hip_last_error(pt_ctx* ctx) { return ctx ? ctx->err.c_str() : "nu
 
 int pt_hip_create(int device, pt_ctx** out)
 {
+    PT_ENTER(nullptr, "pt_hip_create")
     if (!out) return PT_ERR_INVALID;
     *out = nullptr;
     int n = pt_hip_device_count();
@@ -812,6 +1008,7 @@ int pt_hip_create(int device, pt_ctx** out)
     pt_ctx* c = new (std::nothrow) pt_ctx();
     if (!c) return PT_ERR_INVALID;
     c->device = device;
+    c->occ.reserve(64); c->err.reserve(512); // (a frame loop's few shapes and its error texts then fit without a host allocation)
     Bind b(c);
     if (!b.ok) { delete c; return PT_ERR_NO_DEVICE; }
     hipDeviceProp_t prop;
@@ -836,6 +1033,7 @@ int pt_hip_create(int device, pt_ctx** out)
     }
     *out = c;
     return PT_OK;
+    PT_LEAVE
 }
 
 void pt_hip_destroy(pt_ctx* c)
@@ -851,151 +1049,48 @@ void pt_hip_destroy(pt_ctx* c)
     delete c;
 }
 
+// ---- scene upload in two steps: host PREPARE (layouts + tree, no device touched) and per-device COMMIT (copies) ----------
+// The reference builds its tree once per process (src/main.cpp:402) and every worker reads it; a node of 8 GPUs does
+// the same here: pt_node_upload_scene prepares once and commits the result to each device.
+int pt_scene_prepare(const pt_scene_desc* d, pt_prepared** out)
+{
+    if (!out) return PT_ERR_INVALID;
+    *out = nullptr;
+    if (!d) return PT_ERR_INVALID;
+    pt_prepared* P = nullptr;
+    const int st = ptg::guard_status(nullptr, "pt_scene_prepare", [&]() {
+        P = new pt_prepared();
+        return prepare_scene(d, P);
+    });
+    if (st != PT_OK) { delete P; return st; }
+    *out = P;
+    return PT_OK;
+}
+
+void pt_prepared_free(pt_prepared* P) { delete P; }
+
+uint64_t pt_tree_build_count(void) { return g_tree_builds.load(); }
+
+int pt_hip_commit_scene(pt_ctx* ctx, const pt_prepared* P)
+{
+    if (!ctx || !P) return PT_ERR_INVALID;
+    return ptg::guard_status(&ctx->err, "pt_hip_commit_scene", [&]() { return commit_scene(ctx, *P); });
+}
+
 int pt_hip_upload_scene(pt_ctx* ctx, const pt_scene_desc* d)
 {
     if (!ctx || !d) return PT_ERR_INVALID;
-    int st = pth::validate_desc(d);
-    if (st != PT_OK) return st;
-    Bind b(ctx);
-    free_scene(ctx);
-    pth::make_device_camera(d->camera, &ctx->cam);
-    // (1) LDS image of the whole scene, if it can fit beside the accumulators of a 4-wave workgroup
-    const size_t roughBytes = (size_t)d->n_spheres * (16 + 16 + 32 + 2) + (size_t)d->n_planes * 48 + 4096;
-    ctx->lds_ok = false;
-    if (roughBytes <= ctx->lds_limit)
-    {
-        pth::build_blob(d, &ctx->blob);
-        ctx->lds_ok = ctx->blob.f4.size() * 16 + kWavesPerBlock * kAccBytesPerWave <= ctx->lds_limit;
-    }
-    if (ctx->lds_ok)
-    {
-        st = upload_f4(ctx, ctx->blob.f4.data(), ctx->blob.f4.size() * 16, &ctx->blob_dev);
-        if (st != PT_OK) return st;
-        fill_scene_args(&ctx->sc_lds, ctx->blob, ctx->blob_dev, d, d->n_planes);
-        ctx->sc_lds.bvh = BvhView{};
-        ctx->moving = ctx->blob.moving;
-    }
-    // (2) BVH in HBM (always built: it is what PT_FLAG_FORCE_BVH and every scene beyond LDS use) + planes-only LDS image
-    {
-        pth::BvhData bv;
-        pth::build_bvh(d, &bv);
-        pt_scene_desc planesOnly = *d;
-        planesOnly.n_spheres = 0;
-        pth::build_blob(&planesOnly, &ctx->blob_planes);
-        st = upload_f4(ctx, ctx->blob_planes.f4.data(), ctx->blob_planes.f4.size() * 16, &ctx->blob_planes_dev); if (st != PT_OK) return st;
-        // Big trees are read from HBM as 32-byte grid nodes (half the loads per step: the L1 is what binds that kernel);
-        // small ones, resident in L1/L2 and bound by instruction issue, keep the 64-byte float nodes.
-        // ... and from kGridNodeMinSpheres up as 64-byte 4-wide grid nodes over single spheres (MODE_BVH_Q4): half the
-        // dependent fetches per ray.  PT_GRID_NODES (tests / tuning): 0 float nodes, 1 32-byte 2-wide, 2 4-wide over
-        // the binary tree's leaves, 3 4-wide over single spheres (the default for big trees).
-        int gridKind = bv.n_spheres >= kGridNodeMinSpheres ? 3 : 0;
-        if (const char* e = getenv("PT_GRID_NODES")) gridKind = atoi(e);
-        if (gridKind < 0 || gridKind > 3) gridKind = 0;
-        if (bv.n_spheres == 0) gridKind = 0;
-        ctx->bvh_q = gridKind == 1 && bv.n_nodes != 0;
-        ctx->bvh_wide = false;
-        pth::NodeGrid grid{};
-        pth::WideData wd;
-        if (gridKind >= 2)
-        {
-            pth::widen_nodes(bv, d, gridKind == 3, &grid, &wd);
-            // (a tree too deep for the stack's LDS + scratch levels keeps the 2-wide grid nodes)
-            if (wd.n_nodes != 0 && 3u * wd.depth + 1u <= kWideStackLds + kOvfEntries) ctx->bvh_wide = true;
-            else ctx->bvh_q = bv.n_nodes != 0;
-        }
-        if (ctx->bvh_wide)
-        {
-            st = upload_f4(ctx, wd.nodes.data(), wd.nodes.size() * 4, &ctx->nodes_dev); if (st != PT_OK) return st;
-        }
-        else if (ctx->bvh_q)
-        {
-            std::vector<uint32_t> qn;
-            pth::quantise_nodes(bv, &grid, &qn);
-            st = upload_f4(ctx, qn.data(), qn.size() * 4, &ctx->nodes_dev); if (st != PT_OK) return st;
-        }
-        else
-        {
-            st = upload_f4(ctx, bv.nodes.data(), bv.nodes.size() * 4, &ctx->nodes_dev); if (st != PT_OK) return st;
-        }
-        st = upload_f4(ctx, bv.sph.data(), bv.sph.size() * 4, &ctx->sph_dev); if (st != PT_OK) return st;
-        st = upload_f4(ctx, bv.vel.data(), bv.vel.size() * 4, &ctx->vel_dev); if (st != PT_OK) return st;
-        st = upload_f4(ctx, bv.mat.data(), bv.mat.size() * 4, &ctx->mat_dev); if (st != PT_OK) return st;
-        fill_scene_args(&ctx->sc_bvh, ctx->blob_planes, ctx->blob_planes_dev, d, d->n_planes);
-        ctx->sc_bvh.bvh = BvhView{ctx->nodes_dev, ctx->sph_dev, ctx->vel_dev, ctx->mat_dev, ctx->bvh_wide ? wd.root_ref : bv.root_ref, bv.n_spheres,
-                                  {grid.org[0], grid.org[1], grid.org[2]}, {grid.step[0], grid.step[1], grid.step[2]}};
-        ctx->sc_bvh.stack_entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1; // the sentinel + at most one pushed sibling per inner node of a root-to-leaf path (bv.depth of them)
-        if (ctx->bvh_wide)
-        {
-            // up to three pushed siblings per level; the first kWideStackLds levels in LDS, the rest in scratch (pt_device.h)
-            uint32_t capLds = kWideStackLds;
-            if (const char* e = getenv("PT_WIDE_STACK")) { int v = atoi(e); if (v >= 2 && v <= 255) capLds = (uint32_t)v; } // tuning experiments only
-            const uint32_t need = 3u * wd.depth + 1u;
-            ctx->sc_bvh.stack_entries = need < capLds ? (need < 4 ? 4 : need) : capLds;
-            if (need > ctx->sc_bvh.stack_entries + kOvfEntries) { ctx->err = "wide BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
-        }
-        ctx->sc_bvh.leaf_batch = kLeafBatch;
-        int exitEnv = -1;
-        if (const char* e = getenv("PT_EXIT_LANES")) { int v = atoi(e); if (v >= 0 && v <= 64) exitEnv = v; } // tuning experiments only
-        const bool resumable = bv.n_spheres > kResumeMinSpheres;
-
-        int exitMul = -1;
-        if (const char* e = getenv("PT_EXIT_MUL")) { int v = atoi(e); if (v >= 1 && v <= 255) exitMul = v; } // tuning experiments only
-        ctx->sc_bvh.exit_lanes = !resumable ? 0u : pack_exit_rule(exitEnv >= 0 ? (uint32_t)exitEnv : ctx->bvh_wide ? kExitLanesWide : kExitLanesHbm,
-                                                                 exitMul > 0 ? (uint32_t)exitMul : ctx->bvh_wide ? kExitMulWide : kExitMul);
-        if (ctx->bvh_wide) ctx->sc_bvh.leaf_batch = kLeafBatchWide;
-        const uint32_t refillLds = ctx->sc_bvh.refill_min; // (fill_scene_args: the default, or PT_REFILL_MIN)
-        if (!getenv("PT_REFILL_MIN")) ctx->sc_bvh.refill_min = ctx->bvh_wide ? kRefillMinWide : kRefillMinHbm;
-        const uint32_t carryLds = ctx->sc_bvh.carry_max; // (fill_scene_args: the default, or PT_CARRY_MAX)
-        if (!getenv("PT_CARRY_MAX")) ctx->sc_bvh.carry_max = ctx->bvh_wide ? kCarryMaxWide : kCarryMaxHbm;
-        if (const char* e = getenv("PT_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->sc_bvh.leaf_batch = (uint32_t)v; } // tuning experiments only
-        ctx->bvh_nodes = bv.n_nodes; ctx->bvh_depth = bv.depth;
-        ctx->moving = bv.moving;
-        // what pt_hip_build_reference_tree needs later: the spheres as the caller numbered them, and where each one sits now
-        ctx->desc = *d;
-        ctx->h_pos_r.assign(d->sphere_pos_r, d->sphere_pos_r + 4 * (size_t)d->n_spheres);
-        if (d->sphere_vel) ctx->h_vel.assign(d->sphere_vel, d->sphere_vel + 3 * (size_t)d->n_spheres); else ctx->h_vel.clear();
-        ctx->desc.sphere_pos_r = ctx->h_pos_r.data(); ctx->desc.sphere_vel = d->sphere_vel ? ctx->h_vel.data() : nullptr;
-        ctx->desc.sphere_mat_type = nullptr; ctx->desc.sphere_mat_rgba = nullptr; ctx->desc.sphere_mat_param = nullptr;
-        ctx->desc.plane_n_d = nullptr; ctx->desc.plane_mat_type = nullptr; ctx->desc.plane_mat_rgba = nullptr; ctx->desc.plane_mat_param = nullptr;
-        ctx->slot_of_sphere.assign(d->n_spheres, 0u);
-        for (uint32_t slot = 0; slot < bv.n_spheres; ++slot) ctx->slot_of_sphere[pth::f2u(bv.mat[8 * (size_t)slot + 3])] = slot;
-        if (bv.depth + 1 > kBvhStack) { ctx->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
-        // (3) the same tree staged in LDS behind the planes, when planes + tree + payload + 4 waves' stacks fit
-        const uint32_t entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1; // (the binary tree's: sc_bvh may hold the 4-wide tree's figure)
-        // Materials are read once per hit, the tree and the spheres at every step: only the latter are worth LDS, and
-        // the smaller image lets more waves share a CU.
-        const bool matInLds = getenv("PT_MAT_LDS") != nullptr; // tuning experiments only
-        const size_t f4s = ctx->blob_planes.f4.size() + (bv.nodes.size() + bv.sph.size() + bv.vel.size() + (matInLds ? bv.mat.size() : 0)) / 4;
-        ctx->bvh_lds_ok = f4s * 16 + kWavesPerBlock * (kAccBytesPerWave + (size_t)entries * 256) <= ctx->lds_limit;
-        if (ctx->bvh_lds_ok)
-        {
-            std::vector<float> img(ctx->blob_planes.f4.size() * 4);
-            if (!img.empty()) memcpy(img.data(), ctx->blob_planes.f4.data(), img.size() * 4);
-            uint32_t off[4];
-            const std::vector<float>* parts[4] = {&bv.nodes, &bv.sph, &bv.vel, &bv.mat};
-            for (int k = 0; k < 4; ++k)
-            {
-                if (k == 3 && !matInLds) { off[k] = 0xFFFFFFFFu; continue; }
-                off[k] = (uint32_t)(img.size() / 4); img.insert(img.end(), parts[k]->begin(), parts[k]->end());
-            }
-            st = upload_f4(ctx, img.data(), img.size() * 4, &ctx->blob_bvh_dev); if (st != PT_OK) return st;
-            ctx->sc_bvh_lds = ctx->sc_bvh;
-            ctx->sc_bvh_lds.exit_lanes = !resumable ? 0u : pack_exit_rule(exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanes, exitMul > 0 ? (uint32_t)exitMul : kExitMul);
-            ctx->sc_bvh_lds.refill_min = refillLds;
-            if (!getenv("PT_LEAF_BATCH")) ctx->sc_bvh_lds.leaf_batch = kLeafBatchLds;
-            ctx->sc_bvh_lds.carry_max = carryLds;
-            ctx->sc_bvh_lds.blob = ctx->blob_bvh_dev; ctx->sc_bvh_lds.blob_f4 = (uint32_t)(img.size() / 4);
-            for (int k = 0; k < 4; ++k) ctx->sc_bvh_lds.bvh_off[k] = off[k];
-            ctx->sc_bvh_lds.bvh = BvhView{nullptr, nullptr, nullptr, matInLds ? nullptr : ctx->mat_dev, bv.root_ref, bv.n_spheres, {0, 0, 0}, {1, 1, 1}};
-            ctx->sc_bvh_lds.stack_entries = entries;
-        }
-    }
-    ctx->has_scene = true;
-    return PT_OK;
+    return ptg::guard_status(&ctx->err, "pt_hip_upload_scene", [&]() {
+        pt_prepared P;
+        int st = prepare_scene(d, &P);
+        if (st != PT_OK) { ctx->err = P.err; return st; }
+        return commit_scene(ctx, P);
+    });
 }
 
 int pt_hip_build_reference_tree(pt_ctx* ctx, uint32_t rng_skip)
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_build_reference_tree")
     int st = check_scene(ctx);
     if (st != PT_OK) return st;
     const uint32_t n = ctx->desc.n_spheres;
@@ -1028,6 +1123,7 @@ int pt_hip_build_reference_tree(pt_ctx* ctx, uint32_t rng_skip)
     ctx->sc_ref.stack_entries = 3u * (depth + 1u);   // ref_query: three dwords per waiting call
     ctx->has_ref = true;
     return PT_OK;
+    PT_LEAVE
 }
 
 // One frame: the body of pt_hip_render_device and of pt_hip_render_device_static.  `fixed` = the scratch is the
@@ -1103,6 +1199,9 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
     // order of the additions into a pixel is the run's, like the carried paths').  PT_FLAG_REPRODUCIBLE: one partial
     // image per chunk in scratch, folded in chunk order by k_fold_chunks.
     const bool reproducible = (p->flags & PT_FLAG_REPRODUCIBLE) != 0;
+    // PT_FLAG_ACCUMULATE: the frame's sums are ADDED to what accum_dev holds (a progressive render's running sums): the
+    // tiles go in with the same float atomics (no zeroing), a reproducible frame is folded first and added once.
+    const bool addTo = (p->flags & PT_FLAG_ACCUMULATE) != 0;
     const uint64_t frameBytes = (uint64_t)p->width * p->height * 16ull;
     uint32_t nchunks = 0;
     for (;;)
@@ -1119,7 +1218,7 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
     if ((uint64_t)a.ntiles * nchunks > 0xFFFFFF00ull) return PT_ERR_INVALID;
     a.nunits = a.ntiles * nchunks;
     a.partial = nullptr; a.chunk_stride = 0; a.accumulate = 0;
-    if (nchunks > 1 && reproducible)
+    if ((nchunks > 1 || addTo) && reproducible)
     {
         const uint64_t bytes = (uint64_t)nchunks * frameBytes;
         if (fixed)
@@ -1127,8 +1226,10 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
             // same schedule as pt_hip_render_device (the frame must come out bit-identical), so the need is what it is
             if (bytes > kStaticPartialBytes)
             {
-                ctx->err = "pt_hip_render_device_static: a PT_FLAG_REPRODUCIBLE frame of " + std::to_string(p->width) + "x" + std::to_string(p->height) + " in " +
-                           std::to_string(nchunks) + " sample chunks needs " + std::to_string(bytes) + " bytes of scratch, the static maximum is " + std::to_string(kStaticPartialBytes);
+                char msg[256];
+                snprintf(msg, sizeof msg, "pt_hip_render_device_static: a PT_FLAG_REPRODUCIBLE frame of %ux%u in %u sample chunks needs %llu bytes of scratch, the static maximum is %llu",
+                         p->width, p->height, nchunks, (unsigned long long)bytes, (unsigned long long)kStaticPartialBytes);
+                ctx->err.assign(msg);
                 return PT_ERR_UNSUPPORTED;
             }
             a.partial = reinterpret_cast<float*>(ctx->static_scratch + kStaticStatsBytes);
@@ -1146,7 +1247,7 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
         }
         a.chunk_stride = p->width * p->height;
     }
-    else if (nchunks > 1)
+    else if (nchunks > 1 || addTo)
         a.accumulate = 1;
     uint64_t wgs = ((uint64_t)a.nunits + waves - 1) / waves;
     if (wgs > (uint64_t)wgPerCu * ctx->num_cus) wgs = (uint64_t)wgPerCu * ctx->num_cus;
@@ -1157,10 +1258,15 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
     if (nslots > stat_slots) { ctx->err = "launch larger than the statistics buffer"; return PT_ERR_UNSUPPORTED; }
     // One launch of a context in flight at a time: the statistics words (the unit cursor among them), the partial images
     // and the two events are per context.  A launch on another stream waits for the previous one here.
-    if (ctx->timed) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev1, 0));
+    // Under stream capture (a HIP graph being recorded) the context's events stay out of the graph: no wait on the previous
+    // launch, no timing records; pt_hip_last_stats then reports nothing for the captured launch.
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (stream) (void)hipStreamIsCapturing(stream, &capture);
+    const bool capturing = capture != hipStreamCaptureStatusNone;
+    if (ctx->timed && !capturing) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev1, 0));
     HIPCHK(ctx, hipMemsetAsync(stats_dev, 0, (size_t)kStatWords * (1u + nslots) * sizeof(unsigned long long), stream));
-    if (a.accumulate) HIPCHK(ctx, hipMemsetAsync(accum_dev, 0, (size_t)frameBytes, stream));
-    HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
+    if (a.accumulate && !addTo) HIPCHK(ctx, hipMemsetAsync(accum_dev, 0, (size_t)frameBytes, stream));
+    if (!capturing) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     {
         const RenderKernel kern = render_kernel(ctx->moving, mode, a.sc.exit_lanes != 0, !(p->flags & PT_FLAG_REPRODUCIBLE));
         st = set_lds(ctx, kern, lds);
@@ -1173,13 +1279,13 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
         const uint32_t n = p->width * p->height;
         uint32_t blocks = (n + 255) / 256;
         if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(k_fold_chunks, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(a.partial), nchunks, n, reinterpret_cast<float4*>(accum_dev));
+        hipLaunchKernelGGL(k_fold_chunks, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(a.partial), nchunks, n, reinterpret_cast<float4*>(accum_dev), addTo ? 1u : 0u);
     }
     HIPCHK(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_sum_stats, dim3((nslots + 255u) / 256u), dim3(256), 0, stream, stats_dev, nslots);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
-    ctx->timed = true;
+    if (!capturing) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
+    ctx->timed = !capturing;
     ctx->last_stats_dev = stats_dev;
     ctx->last_mode = mode;
     ctx->last = pt_stats{};
@@ -1192,16 +1298,21 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
 
 int pt_hip_render_device(pt_ctx* ctx, const pt_params* p, float* accum_dev, void* stream_)
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_render_device")
     return render_launch(ctx, p, accum_dev, (hipStream_t)stream_, false);
+    PT_LEAVE
 }
 
 int pt_hip_render_device_static(pt_ctx* ctx, const pt_params* p, float* accum_dev, void* stream_)
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_render_device_static")
     return render_launch(ctx, p, accum_dev, (hipStream_t)stream_, true);
+    PT_LEAVE
 }
 
 int pt_hip_render(pt_ctx* ctx, const pt_params* p, float* accum_host)
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_render")
     int st = check_scene(ctx);
     if (st != PT_OK) return st;
     if (!p || !accum_host || p->width == 0 || p->height == 0) return PT_ERR_INVALID;
@@ -1217,10 +1328,12 @@ int pt_hip_render(pt_ctx* ctx, const pt_params* p, float* accum_host)
     if (st != PT_OK) return st;
     HIPCHK(ctx, hipMemcpy(accum_host, ctx->accum_dev, floats * sizeof(float), hipMemcpyDeviceToHost));
     return PT_OK;
+    PT_LEAVE
 }
 
 int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out)
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_last_stats")
     if (!ctx || !out) return PT_ERR_INVALID;
     if (!ctx->timed) return PT_ERR_NO_SCENE;
     Bind b(ctx);
@@ -1245,6 +1358,7 @@ int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out)
     }
     *out = ctx->last;
     return PT_OK;
+    PT_LEAVE
 }
 
 uint32_t pt_chunk_schedule(uint32_t nspp, uint32_t ratio_q16, uint32_t min_spp, uint32_t* out_sizes, uint32_t cap)
@@ -1262,6 +1376,7 @@ uint32_t pt_chunk_schedule(uint32_t nspp, uint32_t ratio_q16, uint32_t min_spp, 
 
 int pt_bvh_selfcheck(const pt_scene_desc* d, uint64_t out8[8])
 {
+    PT_ENTER(nullptr, "pt_bvh_selfcheck")
     if (!d || !out8) return PT_ERR_INVALID;
     for (int i = 0; i < 8; ++i) out8[i] = 0;
     pth::BvhData bv;
@@ -1365,20 +1480,24 @@ int pt_bvh_selfcheck(const pt_scene_desc* d, uint64_t out8[8])
         if (found != bv.n_spheres) ++out8[7];
     }
     return (out8[4] == bv.n_spheres && out8[5] == 0 && out8[6] == 0 && out8[7] == 0) ? PT_OK : PT_ERR_INVALID;
+    PT_LEAVE
 }
 
 int pt_hip_debug_counters(pt_ctx* ctx, uint64_t out16[16])
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_debug_counters")
     if (!ctx || !out16) return PT_ERR_INVALID;
     if (!ctx->timed) return PT_ERR_NO_SCENE;
     Bind b(ctx);
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     HIPCHK(ctx, hipMemcpy(out16, ctx->last_stats_dev, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PT_OK;
+    PT_LEAVE
 }
 
 int pt_hip_resolve_device(pt_ctx* ctx, const float* accum_dev, uint32_t n_pixels, uint32_t spp_total, float* pixels_dev, uint32_t* bgra_dev, void* stream_)
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_resolve_device")
     if (!ctx || !accum_dev || n_pixels == 0 || spp_total == 0) return PT_ERR_INVALID;
     Bind b(ctx);
     const float inv = 1.0f / (float)spp_total; // vectors.cpp:100-103
@@ -1388,11 +1507,13 @@ int pt_hip_resolve_device(pt_ctx* ctx, const float* accum_dev, uint32_t n_pixels
                        reinterpret_cast<float4*>(pixels_dev), bgra_dev);
     HIPCHK(ctx, hipGetLastError());
     return PT_OK;
+    PT_LEAVE
 }
 
 // ------------------------------------------------------------------------------------------------ probes
 int pt_hip_probe_primitives(pt_ctx* ctx, uint32_t n, const float* rays, const float* spheres, const float* planes, float* out_ts, float* out_tp)
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_probe_primitives")
     if (!ctx || !rays || !spheres || !planes || !out_ts || !out_tp) return PT_ERR_INVALID;
     if (n == 0) return PT_OK;
     Bind b(ctx);
@@ -1407,11 +1528,13 @@ int pt_hip_probe_primitives(pt_ctx* ctx, uint32_t n, const float* rays, const fl
     HIPCHK(ctx, hipMemcpy(out_ts, ots.p, n * 4ull, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(out_tp, otp.p, n * 4ull, hipMemcpyDeviceToHost));
     return PT_OK;
+    PT_LEAVE
 }
 
 int pt_hip_probe_hits(pt_ctx* ctx, uint32_t n, const float* rays, const float* times, uint32_t flags,
                       float* out_t, int32_t* out_prim, float* out_point, float* out_normal)
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_probe_hits")
     int st = check_scene(ctx);
     if (st != PT_OK) return st;
     if (!rays || !times || !out_t || !out_prim || !out_point || !out_normal) return PT_ERR_INVALID;
@@ -1435,10 +1558,12 @@ int pt_hip_probe_hits(pt_ctx* ctx, uint32_t n, const float* rays, const float* t
     HIPCHK(ctx, hipMemcpy(out_point, opt.p, n * 12ull, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(out_normal, on.p, n * 12ull, hipMemcpyDeviceToHost));
     return PT_OK;
+    PT_LEAVE
 }
 
 int pt_hip_probe_get_rays(pt_ctx* ctx, uint32_t n, const float* uv, const float* tape, const uint64_t* ofs, float* out_rays)
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_probe_get_rays")
     int st = check_scene(ctx);
     if (st != PT_OK) return st;
     if (!uv || !tape || !ofs || !out_rays) return PT_ERR_INVALID;
@@ -1456,6 +1581,7 @@ int pt_hip_probe_get_rays(pt_ctx* ctx, uint32_t n, const float* uv, const float*
     HIPCHK(ctx, hipDeviceSynchronize());
     HIPCHK(ctx, hipMemcpy(out_rays, dout.p, n * 24ull, hipMemcpyDeviceToHost));
     return PT_OK;
+    PT_LEAVE
 }
 
 int pt_hip_probe_scatter(pt_ctx* ctx, uint32_t n, const float* dirs, const float* points, const float* normals,
@@ -1463,6 +1589,7 @@ int pt_hip_probe_scatter(pt_ctx* ctx, uint32_t n, const float* dirs, const float
                          const float* tape32, const uint64_t* ofs32, const double* tape64, const uint64_t* ofs64,
                          float* out_dir, uint32_t* out_event)
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_probe_scatter")
     if (!ctx) return PT_ERR_INVALID;
     if (!dirs || !points || !normals || !mat_type || !mat_rgba || !mat_param || !tape32 || !ofs32 || !tape64 || !ofs64 || !out_dir || !out_event) return PT_ERR_INVALID;
     if (n == 0) return PT_OK;
@@ -1491,12 +1618,14 @@ int pt_hip_probe_scatter(pt_ctx* ctx, uint32_t n, const float* dirs, const float
     HIPCHK(ctx, hipMemcpy(out_dir, od.p, n * 12ull, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(out_event, oe.p, n * 4ull, hipMemcpyDeviceToHost));
     return PT_OK;
+    PT_LEAVE
 }
 
 int pt_hip_probe_paths(pt_ctx* ctx, uint32_t n, const float* rays, const float* times, uint32_t max_depth, uint32_t flags,
                        const float* tape32, const uint64_t* ofs32, const double* tape64, const uint64_t* ofs64,
                        float* out_rgba, uint32_t* out_segments)
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_probe_paths")
     int st = check_scene(ctx);
     if (st != PT_OK) return st;
     if (!rays || !times || !tape32 || !ofs32 || !tape64 || !ofs64 || !out_rgba) return PT_ERR_INVALID;
@@ -1525,11 +1654,13 @@ int pt_hip_probe_paths(pt_ctx* ctx, uint32_t n, const float* rays, const float* 
     HIPCHK(ctx, hipMemcpy(out_rgba, oc.p, n * 16ull, hipMemcpyDeviceToHost));
     if (out_segments) HIPCHK(ctx, hipMemcpy(out_segments, os.p, n * 4ull, hipMemcpyDeviceToHost));
     return PT_OK;
+    PT_LEAVE
 }
 
 int pt_hip_probe_samples(pt_ctx* ctx, const pt_params* p, uint32_t n, const uint32_t* pixels, const uint32_t* samples,
                          float* out_rgba, uint32_t* out_segments)
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_probe_samples")
     int st = check_scene(ctx);
     if (st != PT_OK) return st;
     if (!p || !pixels || !samples || !out_rgba || p->width == 0 || p->height == 0) return PT_ERR_INVALID;
@@ -1551,10 +1682,12 @@ int pt_hip_probe_samples(pt_ctx* ctx, const pt_params* p, uint32_t n, const uint
     HIPCHK(ctx, hipMemcpy(out_rgba, oc.p, n * 16ull, hipMemcpyDeviceToHost));
     if (out_segments) HIPCHK(ctx, hipMemcpy(out_segments, os.p, n * 4ull, hipMemcpyDeviceToHost));
     return PT_OK;
+    PT_LEAVE
 }
 
 int pt_hip_probe_philox(pt_ctx* ctx, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* out_words)
 {
+    PT_ENTER(ctx ? &ctx->err : nullptr, "pt_hip_probe_philox")
     if (!ctx || !out_words) return PT_ERR_INVALID;
     if (n == 0) return PT_OK;
     Bind b(ctx);
@@ -1565,6 +1698,7 @@ int pt_hip_probe_philox(pt_ctx* ctx, uint64_t seed, uint32_t pixel, uint32_t sam
     HIPCHK(ctx, hipDeviceSynchronize());
     HIPCHK(ctx, hipMemcpy(out_words, o.p, n * 4ull, hipMemcpyDeviceToHost));
     return PT_OK;
+    PT_LEAVE
 }
 
 } // extern "C"

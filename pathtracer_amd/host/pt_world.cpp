@@ -9,7 +9,10 @@
 #include <string.h>
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <new>
+
+#include "../csrc/pt_guard.h"
 
 namespace pt {
 
@@ -371,24 +374,26 @@ extern "C" {
 
 pt_scene* pt_scene_builtin(int id, float aspect, uint32_t n_for_id5)
 {
-    pt_scene* s = new (std::nothrow) pt_scene();
-    if (!s) return nullptr;
-    switch (id)
-    {
-    case 1: pt::init_test_scene_1(&s->world, &s->camera, aspect); break;
-    case 2: pt::init_test_scene_2(&s->world, &s->camera, aspect); break;
-    case 3: pt::init_test_scene_3(&s->world, &s->camera, aspect); break;
-    case 4: pt::init_materials_scene(&s->world, &s->camera, aspect); break;
-    case 5: pt::init_random_spheres_scene(&s->world, &s->camera, aspect, n_for_id5 ? n_for_id5 : 1000000u); break;
-    default: delete s; return nullptr;
-    }
-    pt::flatten(s->world, s->camera, &s->flat);
-    return s;
+    return ptg::guard_ptr<pt_scene>([&]() -> pt_scene* {
+        std::unique_ptr<pt_scene> s(new pt_scene());
+        switch (id)
+        {
+        case 1: pt::init_test_scene_1(&s->world, &s->camera, aspect); break;
+        case 2: pt::init_test_scene_2(&s->world, &s->camera, aspect); break;
+        case 3: pt::init_test_scene_3(&s->world, &s->camera, aspect); break;
+        case 4: pt::init_materials_scene(&s->world, &s->camera, aspect); break;
+        case 5: pt::init_random_spheres_scene(&s->world, &s->camera, aspect, n_for_id5 ? n_for_id5 : 1000000u); break;
+        default: return nullptr;
+        }
+        pt::flatten(s->world, s->camera, &s->flat);
+        return s.release();
+    });
 }
 
 uint32_t pt_reference_bvh(const pt_scene_desc* d, uint32_t rng_skip, uint32_t cap_nodes, float* boxes6, int32_t* links3, uint32_t* order, uint32_t* depth_out)
 {
     if (!d || d->n_spheres == 0 || d->n_spheres > PT_REFERENCE_MAX_SPHERES || !d->sphere_pos_r) return 0;
+    try {
     pt::RefTreeBuilder b;
     b.d = d;
     for (uint32_t i = 0; i < rng_skip; ++i) (void)b.rng.f32();
@@ -405,6 +410,7 @@ uint32_t pt_reference_bvh(const pt_scene_desc* d, uint32_t rng_skip, uint32_t ca
     }
     if (order) memcpy(order, b.order.data(), (size_t)d->n_spheres * sizeof(uint32_t));
     return nn;
+    } catch (...) { return 0; } // (0 nodes = failure, as for a scene the reference cannot hold)
 }
 
 int pt_scene_get_desc(const pt_scene* s, pt_scene_desc* out)
@@ -451,10 +457,11 @@ int pt_scene_save(const pt_scene_desc* d, const char* path)
 pt_scene* pt_scene_load(const char* path)
 {
     if (!path) return nullptr;
-    FILE* f = fopen(path, "r");
+    struct File { FILE* f; ~File() { if (f) fclose(f); } } file{fopen(path, "r")};
+    FILE* f = file.f;
     if (!f) return nullptr;
-    pt_scene* s = new (std::nothrow) pt_scene();
-    if (!s) { fclose(f); return nullptr; }
+    return ptg::guard_ptr<pt_scene>([&]() -> pt_scene* {
+    std::unique_ptr<pt_scene> s(new pt_scene());
     pt::FlatScene& fl = s->flat;
     pt_scene_desc& d = fl.desc;
     bool ok = true, header = false, haveCamera = false, moving = false;
@@ -491,13 +498,13 @@ pt_scene* pt_scene_load(const char* path)
         }
         else ok = false;
     }
-    fclose(f);
-    if (!ok || !header || !haveCamera) { delete s; return nullptr; }
+    if (!ok || !header || !haveCamera) return nullptr;
     d.n_spheres = (uint32_t)fl.type.size(); d.n_planes = (uint32_t)fl.pl_type.size();
     d.sphere_pos_r = fl.pos_r.data(); d.sphere_vel = moving ? fl.vel.data() : nullptr; d.sphere_mat_type = fl.type.data();
     d.sphere_mat_rgba = fl.rgba.data(); d.sphere_mat_param = fl.param.data();
     d.plane_n_d = fl.pl_n_d.data(); d.plane_mat_type = fl.pl_type.data(); d.plane_mat_rgba = fl.pl_rgba.data(); d.plane_mat_param = fl.pl_param.data();
-    return s;
+    return s.release();
+    });
 }
 
 int pt_resolve(const float* sum, uint32_t n, uint32_t spp, float* out)                       // main.cpp:358
@@ -556,7 +563,7 @@ int pt_bmp_write(const char* path, const float* px, uint32_t w, uint32_t h)     
 {
     if (!path || !px || w == 0 || h == 0) return PT_ERR_INVALID;
     uint32_t* packed = new (std::nothrow) uint32_t[(size_t)w * h];
-    if (!packed) return PT_ERR_INVALID;
+    if (!packed) return PT_ERR_NO_MEMORY;
     pt_pack_bgra(px, w * h, packed);
     int st = pt_bmp_write_bgra(path, packed, w, h);
     delete[] packed;

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_exactly_the_header(golden_dir):
     header = open(os.path.join(ROOT, "include", "pt_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|void|uint32_t|const char\*|pt_scene\*|pt_ctx\*)\s+(pt_[a-z0-9_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|void|uint32_t|uint64_t|const char\*|pt_scene\*|pt_ctx\*)\s+(pt_[a-z0-9_]+)\s*\(", header, re.M))
     assert declared == set(pt.EXPORTS), declared ^ set(pt.EXPORTS)
     L = pt.load_library()
     for sym in pt.EXPORTS:

@@ -76,3 +76,46 @@ def test_static_entry_point_refuses_what_does_not_fit(renderer):
     renderer.render_device(p2, acc3.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert bit_equal(acc2.cpu().numpy(), acc3.cpu().numpy())
+
+
+def test_static_entry_point_leaves_device_memory_alone_and_records_into_a_graph(renderer):
+    """No device allocation: the free-memory figure of the device does not move across static calls (first call at a new
+    shape included).  And the call can be RECORDED: captured into a HIP graph (its timing events stay out of the graph),
+    replayed twice, each replay leaves the frame pt_hip_render_device leaves."""
+    torch = pytest.importorskip("torch")
+    w, h, flags = 120, 68, pt.FLAG_REPRODUCIBLE
+    renderer.upload(pt.Scene.builtin(1, w / h))
+    acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    want = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    p = renderer.params(w, h, 0, 24, 50, seed=8, flags=flags)
+    renderer.render_device(p, want.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for shape in ((w, h), (64, 36), (w, h)):
+        q = renderer.params(shape[0], shape[1], 0, 24, 50, seed=8, flags=flags)
+        renderer.render_device_static(q, acc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0, (free0, free1)
+    assert bit_equal(acc.cpu().numpy(), want.cpu().numpy())
+    # graph capture: the call made on the capturing stream; nothing runs until the replay
+    acc.fill_(-3.0)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g.capture_begin()
+        renderer.render_device_static(p, acc.data_ptr(), side.cuda_stream)
+        g.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        acc.fill_(-3.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert bit_equal(acc.cpu().numpy(), want.cpu().numpy())
+    del g
+    # the context still serves ordinary calls, statistics included
+    renderer.render_device(p, acc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert renderer.stats()["samples"] == w * h * 24

@@ -22,7 +22,7 @@ for PMC in \
   "GRBM_GUI_ACTIVE GRBM_COUNT" ; do
   i=$((i+1))
   echo "== pmc pass $i: $PMC"
-  timeout -s KILL 300 rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- $BENCH > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -5 $OUT/pmc$i.log; }
+  timeout -s KILL 300 rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- $BENCH > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed: no further pass in this call"; tail -5 $OUT/pmc$i.log; exit 1; }
 done
 # HBM bytes per launch of this very run -> profiles/traffic.json (bench.py quotes it with the run's tag)
 python3 $ROOT/tools/make_traffic.py $OUT ${PT_TRAFFIC_KEY:-scene1_1920x1080_spp512_d50} $TAG || echo "traffic.json not refreshed"

@@ -71,7 +71,7 @@ def cpu_baseline(scene_id, w, h, depth, spp, threads, n_spheres=0):
                 R3.build_bvh(h3, 0)
                 s3, _ = R3.render(h3, w, h, spp, depth, threads)
                 R3.scene_free(h3)
-                o3 = {"value": round(w * h * spp / s3 / 1e6, 4), "flags": "-O3 -march=native"}
+                o3 = {"value": round(w * h * spp / s3 / 1e6, 4), "flags": "-O3 -march=x86-64-v3 (stands in for -march=native: built in the container, run on this host)"}
             except Exception as e:  # noqa: BLE001 - e.g. built for another CPU
                 o3 = {"value": None, "error": str(e)[:80]}
     else:
@@ -158,6 +158,10 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))   # (no GPU call has been made in this process)
 
+    if os.environ.get("PT_BENCH_WATCHDOG"):   # rehearsals: a rank that hangs says where and ends
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PT_BENCH_WATCHDOG"]), exit=True)
+
     import torch
     import torch.distributed as dist
     import pathtracer_amd as pt
@@ -191,6 +195,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    # (the rehearsal backend reduces through host memory: gloo is a CPU transport)
+    staged = use_dist and os.environ.get("PT_BENCH_BACKEND", "nccl") != "nccl"
+    red_dev = torch.device("cpu") if staged else dev
 
     w, h, depth = args.width, args.height, args.depth
     # this rank's slice of the global sample indices: weak = S each, strong = its part of --spp-total
@@ -219,7 +226,11 @@ def main():
         r.render_device(params, accum.data_ptr(), stream.cuda_stream)
         if ev:
             ev[1].record(stream)
-        if use_dist:
+        if staged:
+            tmp = accum.cpu()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+            accum.copy_(tmp)
+        elif use_dist:
             dist.all_reduce(accum, op=dist.ReduceOp.SUM)  # float accumulation buffer over xGMI, before tonemapping
         if rank == 0:
             r.resolve_device(accum.data_ptr(), w * h, spp_all, 0, bgra.data_ptr(), stream.cuda_stream)
@@ -243,11 +254,11 @@ def main():
     st = r.stats()  # last launch: samples, segments (S-bar), library's own HIP-event time
 
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         seg = torch.tensor([float(st["segments"]), float(st["samples"]), kernel_ms, float(st["node_visits"]), float(st["sphere_tests"])],
-                           dtype=torch.float64, device=dev)
+                           dtype=torch.float64, device=red_dev)
         dist.all_reduce(seg, op=dist.ReduceOp.SUM)
         segs, smps, kernel_ms, nvis, stest = float(seg[0]), float(seg[1]), float(seg[2]) / world, float(seg[3]), float(seg[4])
     else:

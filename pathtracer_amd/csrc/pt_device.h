@@ -573,6 +573,8 @@ constexpr uint32_t kRefLeaf = 0xFFFFFFFFu;
 struct QueryCtx // per-lane scratch and counters of the sphere query
 {
     BvhView bvh; RefView ref; uint32_t* stack; uint32_t searched, nodeVisits, sphereTests, leafBatch;
+    int16_t* stack16;                            // MODE_BVH_LDS: the same per-lane column with 16-bit entries (see "tree in LDS" below)
+    uint32_t laneTests;                          // MODE_BVH_LDS: this LANE's leaf sphere tests (summed over the wave when the kernel ends)
     uint32_t* ovf; uint32_t stackCap;            // MODE_BVH_Q4: levels >= stackCap of the traversal stack live in this per-lane (scratch) array
 #ifdef PT_STAMPS
     uint32_t innerIters, leafIters;              // wave-level trips through the two kinds of traversal step
@@ -597,6 +599,18 @@ PT_DEV uint32_t pt_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readf
 // workgroup of a CU.)
 struct TravState { uint32_t cur; float best; int32_t bestSlot; uint32_t pk; };
 PT_DEV int32_t trav_plane(uint32_t pk) { return (int32_t)((pk >> 8) & 0xFFu) - 1; } // (<= 64 planes; the bits above are the render loop's flags)
+// ---- the tree in LDS (MODE_BVH_LDS; BLK = true below) differs from the trees in HBM in two ways, both to fit more into the
+// LDS that bounds its resident waves:
+//  * 16-bit stack entries.  References are kept sign-extended: an inner node is its index (< 0x8000), a leaf is
+//    0xFFFF8000 | (count - 1) << 12 | leaf index (the sign extension of the 16-bit entry 0x8000 | ...; bit 14 stays 0), the
+//    sentinel is all ones in both widths -- so a push is a 16-bit store of the low half and a pop a sign-extending load, no
+//    conversion, and `cur & kBvhLeafFlag` / `cur == kBvhDone` mean what they mean for the 32-bit references.
+//  * leaf blocks.  A leaf's (up to four) spheres sit in one structure-of-arrays block {cx[4], cy[4], cz[4], r2[4]} (+
+//    {vx[4], vy[4], vz[4]} when spheres move): the conservative filter runs over all four at once in packed FP32, and only
+//    the candidates it leaves get the exact test, one per trip of a short loop.  An unused slot has r2 = -1e30 (never a
+//    candidate).  Sphere "slots" are 4 x leaf + position; the materials in HBM are laid out to match.
+constexpr uint32_t kLdsLeafBase = 0xFFFF8000u;
+template <bool BLK = false>
 PT_DEV void trav_begin(const BvhView& b, float tLimit, int32_t planeIdx, bool live, const QueryCtx& q, TravState& ts)
 {
     ts.best = tLimit;                  // a plane hit found earlier wins ties against spheres (main.cpp:204)
@@ -604,7 +618,7 @@ PT_DEV void trav_begin(const BvhView& b, float tLimit, int32_t planeIdx, bool li
     // The stack pointer is the LDS address itself (this lane's column, 64 dwords per level); level 0 holds a sentinel,
     // so "pop" needs no emptiness test: popping the sentinel ends the lane's traversal.
     ts.pk = (uint32_t)(planeIdx + 1) << 8;
-    *q.stack = kBvhDone;
+    if (BLK) *q.stack16 = (int16_t)-1; else *q.stack = kBvhDone;
     // A lane without a live path holds a stale ray: it starts on the sentinel, so it cannot keep the wave in the loop.
     ts.cur = (live && b.n_spheres != 0) ? b.root_ref : kBvhDone;
 }
@@ -616,9 +630,12 @@ PT_DEV void trav_begin(const BvhView& b, float tLimit, int32_t planeIdx, bool li
 // will have produced by then.  (Measured on book-1: 33 % of the inner steps and 44 % of the leaf steps of a
 // run-to-completion traversal are executed for fewer than 8 lanes.)
 constexpr uint32_t pack_exit_rule(uint32_t minActive, uint32_t doneMul) { return minActive ? (minActive | (doneMul << 8)) : 0u; }
-template <bool MOVING, bool CONE, bool QN, bool FLAT_EXACT>
+template <bool MOVING, bool CONE, bool QN, bool FLAT_EXACT, bool BLK = false>
 PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, QueryCtx& q, TravState& ts, uint32_t exitRule)
 {
+    // stack entries: 32-bit references, or (BLK) their low halves -- a pop sign-extends (see above)
+    using StackT = typename std::conditional<BLK, int16_t, int32_t>::type;
+    StackT* const sbase = BLK ? reinterpret_cast<StackT*>(q.stack16) : reinterpret_cast<StackT*>(q.stack);
     const uint32_t minActive = exitRule & 255u, doneMul = exitRule >> 8; // (see pack_exit_rule)
     const uint32_t leafBatch = q.leafBatch;
 #ifdef PT_STAMPS
@@ -656,7 +673,7 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
         r2x *= b.gstep[0]; r2y *= b.gstep[1]; r2z *= b.gstep[2];
     }
     // All lanes run the loops below together (their exits are wave-uniform), which keeps the two tallies in scalar registers.
-    uint32_t* sp = q.stack + (ts.pk & 255u) * 64u;
+    StackT* sp = sbase + (ts.pk & 255u) * 64u;
     uint32_t cur = ts.cur;
     bool leave = false;
     // Two kinds of step, and a wave pays for both whenever its lanes disagree.  Leaf steps are the dear ones (up to
@@ -706,12 +723,12 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
                 if (hitL && hitR)
                 {
                     const bool leftFirst = nearL <= nearR;
-                    sp += 64; *sp = leftFirst ? refR : refL;
+                    sp += 64; *sp = (StackT)(leftFirst ? refR : refL);
                     cur = leftFirst ? refL : refR;
                 }
                 else if (hitL) cur = refL;
                 else if (hitR) cur = refR;
-                else { cur = *sp; if (cur != kBvhDone) sp -= 64; }
+                else { cur = (uint32_t)(int32_t)*sp; if (cur != kBvhDone) sp -= 64; }
             }
         }
         PT_QSTAMP(qs1);
@@ -729,6 +746,70 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
 #endif
         // ---- leaf steps: every lane that waits at a leaf
         const bool atLeaf = (cur & kBvhLeafFlag) && cur != kBvhDone;
+        if constexpr (BLK)
+        {
+            // the leaf's block: the filter of sphere_clearly_missed over its four slots at once, in packed FP32
+            uint32_t cand = 0;
+            const uint32_t leaf = cur & 0x0FFFu;
+            if (atLeaf)
+            {
+#pragma clang fp contract(fast)
+                q.laneTests += ((cur >> 12) & 3u) + 1u;
+                const f32x2 ox = {ray.o.x, ray.o.x}, oy = {ray.o.y, ray.o.y}, oz = {ray.o.z, ray.o.z};
+                const f32x2 dx = {ray.d.x, ray.d.x}, dy = {ray.d.y, ray.d.y}, dz = {ray.d.z, ray.d.z};
+                const float2* blk2 = reinterpret_cast<const float2*>(b.sph + 4 * leaf);
+                // two slots at a time (a rolled loop: all four at once want more registers than the kernel's budget has)
+#pragma nounroll
+                for (uint32_t hh = 0; hh < 2u; ++hh)
+                {
+                    const float2 X = blk2[hh], Y = blk2[2 + hh], Z = blk2[4 + hh], R = blk2[6 + hh];
+                    f32x2 cx = {X.x, X.y}, cy = {Y.x, Y.y}, cz = {Z.x, Z.y};
+                    if (MOVING)
+                    {
+                        const float2* vb2 = reinterpret_cast<const float2*>(b.vel + 3 * leaf);
+                        const float2 VX = vb2[hh], VY = vb2[2 + hh], VZ = vb2[4 + hh];
+                        const f32x2 tt = {time, time};
+                        cx = f32x2{VX.x, VX.y} * tt + cx; cy = f32x2{VY.x, VY.y} * tt + cy; cz = f32x2{VZ.x, VZ.y} * tt + cz;
+                    }
+                    const f32x2 gx = ox - cx, gy = oy - cy, gz = oz - cz;
+                    const f32x2 hb = gx * dx + gy * dy + gz * dz;
+                    const f32x2 oo = gx * gx + gy * gy + gz * gz;
+                    const f32x2 h2 = hb * hb;
+                    const f32x2 ds = h2 - (oo - f32x2{R.x, R.y});
+                    const f32x2 th = (h2 + oo) * f32x2{-1e-5f, -1e-5f};
+                    // (a NaN -- the stale ray of a lane without a path never gets here -- would make the slot a candidate: safe)
+                    cand |= ((!(ds.x < th.x) ? 1u : 0u) | (!(ds.y < th.y) ? 2u : 0u)) << (2u * hh);
+                }
+            }
+            // the exact (reference-arithmetic) test for what the filter left, one candidate per lane and trip
+            for (;;)
+            {
+                if (pt_ballot(cand != 0u) == 0ull) break;
+#ifdef PT_STAMPS
+                ++q.leafSlotIters; ++q.leafExactIters;
+#endif
+                if (cand != 0u)
+                {
+                    const uint32_t k = (uint32_t)__builtin_ctz(cand);
+                    cand &= cand - 1u;
+                    const float* blk = reinterpret_cast<const float*>(b.sph + 4 * leaf) + k;
+                    V3 c = v3(blk[0], blk[4], blk[8]);
+                    const float r2 = blk[12];
+                    if (MOVING) { const float* vb = reinterpret_cast<const float*>(b.vel + 3 * leaf) + k; c = add(c, mul(v3(vb[0], vb[4], vb[8]), time)); } // main.cpp:66
+                    const float t = intersect_sphere_exact(ray, c, r2);
+                    if (t > kMinT && t <= best)
+                    {
+                        const uint32_t slot = 4u * leaf + k;
+                        bool take = t < best;
+                        if (!take && bestSlot >= 0)
+                            take = __float_as_uint(b.mat[2 * slot].w) < __float_as_uint(b.mat[2 * (uint32_t)bestSlot].w);
+                        if (take) { best = t; cull = t * kCullSlack; bestSlot = (int32_t)slot; }
+                    }
+                }
+            }
+        }
+        else
+        {
         const uint32_t first = cur & 0x0FFFFFFFu, count = atLeaf ? ((cur >> 28) & 7u) + 1u : 0u;
         for (uint32_t k = 0;; ++k)
         {
@@ -766,14 +847,15 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
                 }
             }
         }
-        if (atLeaf) { cur = *sp; if (cur != kBvhDone) sp -= 64; }
+        } // !BLK
+        if (atLeaf) { cur = (uint32_t)(int32_t)*sp; if (cur != kBvhDone) sp -= 64; }
         PT_QSTAMP(qs2);
 #ifdef PT_STAMPS
         q.cycLeaf += qs2 - qs1;
 #endif
     }
     ts.cur = cur; ts.best = best; ts.bestSlot = bestSlot;
-    ts.pk = (ts.pk & ~255u) | ((uint32_t)(sp - q.stack) >> 6);
+    ts.pk = (ts.pk & ~255u) | ((uint32_t)(sp - sbase) >> 6);
 }
 // ---- the same traversal over 4-wide grid nodes (MODE_BVH_Q4; host: pt_bvh.h widen_nodes) ------------------------------
 // One 64-byte fetch decides up to four subtrees; the hit children are ordered near to far by one sorting network over
@@ -922,9 +1004,19 @@ PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live
     ts.pk = (ts.pk & ~255u) | level;
 }
 // The winner's centre, as the leaf test saw it.
-template <bool MOVING> PT_DEV V3 trav_centre(const BvhView& b, int32_t slot, float time)
+template <bool MOVING, bool BLK = false> PT_DEV V3 trav_centre(const BvhView& b, int32_t slot, float time)
 {
     V3 centre = v3(0, 0, 0);
+    if (BLK)
+    {
+        if (slot >= 0)   // slot = 4 x leaf + position: component `position` of the leaf's block
+        {
+            const float* blk = reinterpret_cast<const float*>(b.sph + ((uint32_t)slot & ~3u)) + ((uint32_t)slot & 3u);
+            centre = v3(blk[0], blk[4], blk[8]);
+            if (MOVING) { const float* vb = reinterpret_cast<const float*>(b.vel + 3u * ((uint32_t)slot >> 2)) + ((uint32_t)slot & 3u); centre = add(centre, mul(v3(vb[0], vb[4], vb[8]), time)); }
+        }
+        return centre;
+    }
     if (slot >= 0)
     {
         const float4 sd = b.sph[(uint32_t)slot];
@@ -954,7 +1046,7 @@ template <bool MOVING, int MODE>
 PT_DEV void run_traversal(const BvhView& b, const Ray& ray, float time, bool live, QueryCtx& q, TravState& ts, uint32_t minActive)
 {
     if constexpr (MODE == MODE_BVH_Q4) bvh_run_wide<MOVING>(b, ray, time, live, q, ts, minActive);
-    else bvh_run<MOVING, mode_uses_cone(MODE), MODE == MODE_BVH_Q, mode_in_hbm(MODE)>(b, ray, time, live, q, ts, minActive);
+    else bvh_run<MOVING, mode_uses_cone(MODE), MODE == MODE_BVH_Q, mode_in_hbm(MODE), MODE == MODE_BVH_LDS>(b, ray, time, live, q, ts, minActive);
 }
 
 
@@ -1094,7 +1186,7 @@ PT_DEV Hit make_hit(const SceneView& s, const Ray& ray, int32_t obj, float t, V3
     return h;
 }
 // ... for the BVH kernels: from a finished traversal (best = the plane's t unless a sphere beat it)
-template <bool MOVING> PT_DEV Hit make_hit_bvh(const SceneView& s, const Ray& ray, float time, const QueryCtx& q, const TravState& ts)
+template <bool MOVING, bool BLK = false> PT_DEV Hit make_hit_bvh(const SceneView& s, const Ray& ray, float time, const QueryCtx& q, const TravState& ts)
 {
     const int32_t planeIdx = trav_plane(ts.pk);
     const int32_t obj = ts.bestSlot;
@@ -1103,7 +1195,7 @@ template <bool MOVING> PT_DEV Hit make_hit_bvh(const SceneView& s, const Ray& ra
     if (obj >= 0) { sphereMat = load_material(q.bvh.mat, (uint32_t)obj); origIndex = __float_as_uint(q.bvh.mat[2 * (uint32_t)obj].w); }
     // a sphere is recorded only when its t is below the plane's (ties stay with the plane), so with obj >= 0 the plane's
     // t is anything above ts.best, and without it ts.best still is the plane's t
-    return make_hit(s, ray, obj, ts.best, trav_centre<MOVING>(q.bvh, obj, time), sphereMat, origIndex, planeIdx, obj >= 0 ? kF32Max : ts.best);
+    return make_hit(s, ray, obj, ts.best, trav_centre<MOVING, BLK>(q.bvh, obj, time), sphereMat, origIndex, planeIdx, obj >= 0 ? kF32Max : ts.best);
 }
 template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, const Ray& ray, float time, bool live, QueryCtx& q)
 {
@@ -1114,9 +1206,9 @@ template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, cons
     if (mode_is_bvh(MODE))
     {
         TravState ts;
-        trav_begin(q.bvh, planeT, planeIdx, live, q, ts);
+        trav_begin<MODE == MODE_BVH_LDS>(q.bvh, planeT, planeIdx, live, q, ts);
         run_traversal<MOVING, MODE>(q.bvh, ray, time, live, q, ts, 0u);
-        return make_hit_bvh<MOVING>(s, ray, time, q, ts);
+        return make_hit_bvh<MOVING, MODE == MODE_BVH_LDS>(s, ray, time, q, ts);
     }
     if (MODE == MODE_REF)
     {

@@ -62,6 +62,8 @@ template <int MODE> __device__ __forceinline__ QueryCtx make_query(const SceneAr
     }
     q.ref = a.ref;
     q.ovf = nullptr; q.stackCap = a.stack_entries;
+    // MODE_BVH_LDS: the wave's stack area (stack_entries x 64 dwords) holds 2 x stack_entries levels of 16-bit entries
+    q.stack16 = reinterpret_cast<int16_t*>(stackBase - (threadIdx.x & 63u)) + (threadIdx.x & 63u); q.laneTests = 0;
     q.stack = stackBase; q.searched = 0; q.nodeVisits = 0; q.sphereTests = 0; q.leafBatch = a.leaf_batch;
 #ifdef PT_STAMPS
     q.innerIters = 0; q.leafIters = 0; q.cycInner = 0; q.cycLeaf = 0; q.leafSlotIters = 0; q.leafExactIters = 0;
@@ -252,11 +254,11 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
                 {
                     int32_t planeIdx = -1;
                     const float planeT = closest_plane(s, ray, &planeIdx);
-                    trav_begin(qc.bvh, planeT, planeIdx, alive, qc, ts);
+                    trav_begin<MODE == MODE_BVH_LDS>(qc.bvh, planeT, planeIdx, alive, qc, ts);
                 }
                 run_traversal<MOVING, MODE>(qc.bvh, ray, time, alive, qc, ts, a.sc.exit_lanes);
                 ready = alive && ts.cur == kBvhDone;
-                if (ready) h = make_hit_bvh<MOVING>(s, ray, time, qc, ts);
+                if (ready) h = make_hit_bvh<MOVING, MODE == MODE_BVH_LDS>(s, ray, time, qc, ts);
             }
             else
                 h = closest_hit<MOVING, MODE>(s, ray, time, alive, qc);
@@ -339,7 +341,8 @@ __device__ __forceinline__ void render_body(const RenderArgs& a)
     // ---- statistics: every wave leaves its tallies in a slot of its own (plain stores; k_sum_stats adds the slots up).
     // Atomics on shared counters would be ~36 000 same-address operations in the launch's last microseconds: measured,
     // they were 0.7 ms -- the whole fixed cost of a small launch.
-    for (int o = 32; o > 0; o >>= 1) segs += __shfl_xor(segs, o);
+    for (int o = 32; o > 0; o >>= 1) { segs += __shfl_xor(segs, o); qc.laneTests += __shfl_xor(qc.laneTests, o); }
+    if (MODE == MODE_BVH_LDS) qc.sphereTests = qc.laneTests;
     if (lane == 0)
     {
         unsigned long long* slot = a.stats + kStatWords * (1u + waveId);
@@ -578,6 +581,7 @@ struct pt_ctx
     DeviceCamera cam{};          // folded camera of the uploaded scene (probe_get_rays; the kernels read the copy in the scene image)
     float4* blob_dev = nullptr; float4* blob_planes_dev = nullptr; float4* blob_bvh_dev = nullptr; // brute-force image, planes only, planes + tree
     float4* nodes_dev = nullptr; float4* sph_dev = nullptr; float4* vel_dev = nullptr; float4* mat_dev = nullptr;
+    float4* mat_lds_dev = nullptr;  // materials in the order of the LDS tree's leaf blocks
     uint32_t bvh_nodes = 0, bvh_depth = 0;
     SceneArgs sc_lds{}, sc_bvh{}, sc_bvh_lds{}, sc_ref{};
     pt_scene_desc desc{};                       // the uploaded scene's description: COPIES of the caller's arrays (below), for pt_hip_build_reference_tree
@@ -608,11 +612,12 @@ struct pt_prepared
 {
     std::string err;
     DeviceCamera cam{};
-    bool moving = false, lds_ok = false, bvh_lds_ok = false, bvh_q = false, bvh_wide = false, mat_in_lds = false;
+    bool moving = false, lds_ok = false, bvh_lds_ok = false, bvh_q = false, bvh_wide = false;
     pth::Blob blob, blob_planes;           // brute-force image of the whole scene (if it fits LDS); planes + camera only
     std::vector<float> nodes_f;            // the tree read from HBM: 64-byte float nodes ...
     std::vector<uint32_t> nodes_u;         // ... or grid nodes (32-byte 2-wide / 64-byte 4-wide)
     std::vector<float> sph, vel, mat;      // sphere payload in leaf order
+    std::vector<float> mat_lds;            // the materials once more in the order of the LDS tree's leaf blocks (slot = 4 x leaf + position)
     std::vector<float> bvh_lds_img;        // planes + tree + spheres staged in LDS by the MODE_BVH_LDS kernels
     SceneArgs sc_lds{}, sc_bvh{}, sc_bvh_lds{};
     uint32_t bvh_nodes = 0, bvh_depth = 0;
@@ -772,7 +777,7 @@ struct DevBuf
 
 void free_scene(pt_ctx* c)
 {
-    float4** ptrs[] = {&c->blob_dev, &c->blob_planes_dev, &c->blob_bvh_dev, &c->nodes_dev, &c->sph_dev, &c->vel_dev, &c->mat_dev};
+    float4** ptrs[] = {&c->blob_dev, &c->blob_planes_dev, &c->blob_bvh_dev, &c->nodes_dev, &c->sph_dev, &c->vel_dev, &c->mat_dev, &c->mat_lds_dev};
     for (float4** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     if (c->ref_nodes_dev) { (void)hipFree(c->ref_nodes_dev); c->ref_nodes_dev = nullptr; }
     c->has_ref = false;
@@ -893,25 +898,49 @@ int prepare_scene(const pt_scene_desc* d, pt_prepared* P)
     P->slot_of_sphere.assign(d->n_spheres, 0u);
     for (uint32_t slot = 0; slot < bv.n_spheres; ++slot) P->slot_of_sphere[pth::f2u(bv.mat[8 * (size_t)slot + 3])] = slot;
     if (bv.depth + 1 > kBvhStack) { P->err = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
-    // (3) the same tree staged in LDS behind the planes, when planes + tree + payload + 4 waves' stacks fit
-    const uint32_t entries = bv.depth + 1 < 4 ? 4 : bv.depth + 1; // (the binary tree's: sc_bvh may hold the 4-wide tree's figure)
-    // Materials are read once per hit, the tree and the spheres at every step: only the latter are worth LDS, and
-    // the smaller image lets more waves share a CU.
-    P->mat_in_lds = getenv("PT_MAT_LDS") != nullptr; // tuning experiments only
-    const size_t f4s = P->blob_planes.f4.size() + (bv.nodes.size() + bv.sph.size() + bv.vel.size() + (P->mat_in_lds ? bv.mat.size() : 0)) / 4;
-    P->bvh_lds_ok = f4s * 16 + kWavesPerBlock * (kAccBytesPerWave + (size_t)entries * 256) <= kMaxLdsBytes;
+    // (3) the same tree staged in LDS behind the planes, when planes + tree + leaf blocks + 4 waves' stacks fit.  The LDS
+    // flavour (pt_device.h, "the tree in LDS"): compact references, 16-bit stack entries (two levels per dword and lane),
+    // the spheres as one structure-of-arrays block per leaf; materials stay in HBM (read once per hit), in block order.
+    const uint32_t levels = bv.depth + 1 < 4 ? 4 : bv.depth + 1;  // the sentinel + at most one pushed sibling per inner node of a root-to-leaf path
+    const uint32_t entries = (levels + 1) / 2;                     // ... in dwords per lane
+    std::vector<float> ldsNodes(bv.nodes), blocks, velBlocks;
+    uint32_t nLeaves = 0;
+    bool blocksOk = bv.n_nodes < 0x8000u;
+    auto add_leaf = [&](uint32_t ref) -> uint32_t {
+        const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 7u) + 1u, leaf = nLeaves++;
+        if (count > 4u || leaf >= 0x1000u || (uint64_t)first + count > bv.n_spheres) { blocksOk = false; return kLdsLeafBase; }
+        blocks.resize(16 * (size_t)nLeaves); P->mat_lds.resize(32 * (size_t)nLeaves, 0.0f);
+        if (bv.moving) velBlocks.resize(12 * (size_t)nLeaves, 0.0f);
+        float* blk = blocks.data() + 16 * (size_t)leaf;
+        for (uint32_t k = 0; k < 4u; ++k)
+        {
+            const bool real = k < count;
+            const float* sp = bv.sph.data() + 4 * (size_t)(first + (real ? k : 0u));   // an unused slot: the leaf's first centre, r2 = -1e30 (never a candidate)
+            blk[k] = sp[0]; blk[4 + k] = sp[1]; blk[8 + k] = sp[2]; blk[12 + k] = real ? sp[3] : -1.0e30f;
+            float* m = P->mat_lds.data() + 8 * (size_t)(4u * leaf + k);
+            if (real) memcpy(m, bv.mat.data() + 8 * (size_t)(first + k), 32); else m[3] = pth::u2f(0xFFFFFFFFu);
+            if (bv.moving && real) { const float* v = bv.vel.data() + 4 * (size_t)(first + k); float* vb = velBlocks.data() + 12 * (size_t)leaf; vb[k] = v[0]; vb[4 + k] = v[1]; vb[8 + k] = v[2]; }
+        }
+        return kLdsLeafBase | ((count - 1u) << 12) | leaf;
+    };
+    uint32_t ldsRoot = 0;
+    if (bv.n_spheres != 0 && bv.n_nodes == 0) ldsRoot = add_leaf(bv.root_ref);
+    for (uint32_t node = 0; node < bv.n_nodes; ++node)
+        for (int c = 12; c <= 13; ++c)
+        {
+            const uint32_t ref = pth::f2u(ldsNodes[16 * (size_t)node + c]);
+            if (ref & pth::kLeafFlag) ldsNodes[16 * (size_t)node + c] = pth::u2f(add_leaf(ref));
+        }
+    const size_t f4s = P->blob_planes.f4.size() + (ldsNodes.size() + blocks.size() + velBlocks.size()) / 4;
+    P->bvh_lds_ok = blocksOk && f4s * 16 + kWavesPerBlock * (kAccBytesPerWave + (size_t)entries * 256) <= kMaxLdsBytes;
     if (P->bvh_lds_ok)
     {
         std::vector<float>& img = P->bvh_lds_img;
         img.resize(P->blob_planes.f4.size() * 4);
         if (!img.empty()) memcpy(img.data(), P->blob_planes.f4.data(), img.size() * 4);
-        uint32_t off[4];
-        const std::vector<float>* parts[4] = {&bv.nodes, &bv.sph, &bv.vel, &bv.mat};
-        for (int k = 0; k < 4; ++k)
-        {
-            if (k == 3 && !P->mat_in_lds) { off[k] = 0xFFFFFFFFu; continue; }
-            off[k] = (uint32_t)(img.size() / 4); img.insert(img.end(), parts[k]->begin(), parts[k]->end());
-        }
+        uint32_t off[4] = {0, 0, 0, 0xFFFFFFFFu};
+        const std::vector<float>* parts[3] = {&ldsNodes, &blocks, &velBlocks};
+        for (int k = 0; k < 3; ++k) { off[k] = (uint32_t)(img.size() / 4); img.insert(img.end(), parts[k]->begin(), parts[k]->end()); }
         P->sc_bvh_lds = P->sc_bvh;
         P->sc_bvh_lds.exit_lanes = !resumable ? 0u : pack_exit_rule(exitEnv >= 0 ? (uint32_t)exitEnv : kExitLanes, exitMul > 0 ? (uint32_t)exitMul : kExitMul);
         P->sc_bvh_lds.refill_min = refillLds;
@@ -919,9 +948,11 @@ int prepare_scene(const pt_scene_desc* d, pt_prepared* P)
         P->sc_bvh_lds.carry_max = carryLds;
         P->sc_bvh_lds.blob = nullptr; P->sc_bvh_lds.blob_f4 = (uint32_t)(img.size() / 4);
         for (int k = 0; k < 4; ++k) P->sc_bvh_lds.bvh_off[k] = off[k];
-        P->sc_bvh_lds.bvh = BvhView{nullptr, nullptr, nullptr, nullptr, bv.root_ref, bv.n_spheres, {0, 0, 0}, {1, 1, 1}};
+        P->sc_bvh_lds.bvh = BvhView{nullptr, nullptr, nullptr, nullptr, ldsRoot, bv.n_spheres, {0, 0, 0}, {1, 1, 1}};
         P->sc_bvh_lds.stack_entries = entries;
     }
+    else
+        P->mat_lds.clear();
     if (!P->bvh_wide && !P->bvh_q) P->nodes_f.swap(bv.nodes);
     P->sph.swap(bv.sph); P->vel.swap(bv.vel); P->mat.swap(bv.mat);
     return PT_OK;
@@ -960,9 +991,10 @@ int commit_scene(pt_ctx* ctx, const pt_prepared& P)
     if (P.bvh_lds_ok)
     {
         st = upload_f4(ctx, P.bvh_lds_img.data(), P.bvh_lds_img.size() * 4, &ctx->blob_bvh_dev); if (st != PT_OK) return st;
+        st = upload_f4(ctx, P.mat_lds.data(), P.mat_lds.size() * 4, &ctx->mat_lds_dev); if (st != PT_OK) return st;
         ctx->sc_bvh_lds = P.sc_bvh_lds;
         ctx->sc_bvh_lds.blob = ctx->blob_bvh_dev;
-        ctx->sc_bvh_lds.bvh.mat = P.mat_in_lds ? nullptr : ctx->mat_dev;
+        ctx->sc_bvh_lds.bvh.mat = ctx->mat_lds_dev;
     }
     ctx->has_scene = true;
     return PT_OK;

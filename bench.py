@@ -281,7 +281,7 @@ def main():
         value = samples_per_step * args.steps / elapsed / 1e6
         sbar = segs / smps
         moving = scene.vel is not None
-        kernel_name = {0: "k_render<brute force, scene in LDS>", 1: "k_render<BVH in HBM>", 2: "k_render<strict search>", 3: "k_render<BVH in LDS>"}[st["kernel"]]
+        kernel_name = {0: "k_render<brute force, scene in LDS>", 1: "k_render<BVH in HBM>", 2: "k_render<strict search>", 3: "k_render<BVH in LDS>", 5: "k_render<straight loop over leaf blocks, no tree>"}[st["kernel"]]
         is_bvh = st["kernel"] in (1, 3)
         # an inner-node visit tests every child box it holds (2 or 4 x 32 FLOP); leaf tests are per sphere
         f_sample = flops_per_sample(sbar, scene.n_spheres, scene.n_planes, moving, float(st["node_width"] or 2) * nvis / segs, stest / segs) if is_bvh else \

@@ -126,7 +126,7 @@ typedef struct pt_stats {
     uint64_t wave_iterations; /* trips of the per-wave segment loop; lane utilisation = segments / (64 * wave_iterations) */
     uint64_t phase_cycles[3]; /* diagnostic builds (-DPT_STAMPS) only: shader cycles in refill / closest-hit / shading; else 0 */
     double kernel_ms;       /* HIP-event time of the render kernel on its stream */
-    uint32_t kernel;        /* 0 = LDS brute force (fast), 1 = BVH in HBM, 2 = LDS brute force (strict), 3 = BVH in LDS, 4 = reference tree + pairwise combine */
+    uint32_t kernel;        /* 0 = LDS brute force (fast), 1 = BVH in HBM, 2 = LDS brute force (strict), 3 = BVH in LDS, 4 = reference tree + pairwise combine, 5 = straight loop over leaf blocks (scenes of at most 8 spheres) */
     uint32_t node_bytes;    /* bytes per tree node the BVH kernels read: 64 (float boxes, or four 16-bit grid boxes) or 32 (two 16-bit grid boxes); 0 without a tree */
     uint32_t node_width;    /* child boxes per node: 2, or 4 (big trees in HBM); 0 without a tree */
     uint32_t reserved;

@@ -623,6 +623,79 @@ PT_DEV void trav_begin(const BvhView& b, float tLimit, int32_t planeIdx, bool li
     ts.cur = (live && b.n_spheres != 0) ? b.root_ref : kBvhDone;
 }
 
+// One leaf block against one ray (lanes with !active ride along): the conservative filter of sphere_clearly_missed over
+// the block's four slots in packed FP32, then the exact (reference-arithmetic) test for the candidates it leaves, one per
+// lane and trip of a wave-uniform loop.  Updates the lane's closest hit (slot = 4 x block + position).
+template <bool MOVING>
+PT_DEV void block_test(const BvhView& b, uint32_t leaf, bool active, const Ray& ray, float time, QueryCtx& q, float& best, float& cull, int32_t& bestSlot)
+{
+    uint32_t cand = 0;
+    if (active)
+    {
+#pragma clang fp contract(fast)
+        const f32x2 ox = {ray.o.x, ray.o.x}, oy = {ray.o.y, ray.o.y}, oz = {ray.o.z, ray.o.z};
+        const f32x2 dx = {ray.d.x, ray.d.x}, dy = {ray.d.y, ray.d.y}, dz = {ray.d.z, ray.d.z};
+        const float2* blk2 = reinterpret_cast<const float2*>(b.sph + 4 * leaf);
+        // two slots at a time (a rolled loop: all four at once want more registers than the kernel's budget has)
+#pragma nounroll
+        for (uint32_t hh = 0; hh < 2u; ++hh)
+        {
+            const float2 X = blk2[hh], Y = blk2[2 + hh], Z = blk2[4 + hh], R = blk2[6 + hh];
+            f32x2 cx = {X.x, X.y}, cy = {Y.x, Y.y}, cz = {Z.x, Z.y};
+            if (MOVING)
+            {
+                const float2* vb2 = reinterpret_cast<const float2*>(b.vel + 3 * leaf);
+                const float2 VX = vb2[hh], VY = vb2[2 + hh], VZ = vb2[4 + hh];
+                const f32x2 tt = {time, time};
+                cx = f32x2{VX.x, VX.y} * tt + cx; cy = f32x2{VY.x, VY.y} * tt + cy; cz = f32x2{VZ.x, VZ.y} * tt + cz;
+            }
+            const f32x2 gx = ox - cx, gy = oy - cy, gz = oz - cz;
+            const f32x2 hb = gx * dx + gy * dy + gz * dz;
+            const f32x2 oo = gx * gx + gy * gy + gz * gz;
+            const f32x2 h2 = hb * hb;
+            const f32x2 ds = h2 - (oo - f32x2{R.x, R.y});
+            const f32x2 th = (h2 + oo) * f32x2{-1e-5f, -1e-5f};
+            // (a NaN -- the stale ray of a lane without a path never gets here -- would make the slot a candidate: safe)
+            cand |= ((!(ds.x < th.x) ? 1u : 0u) | (!(ds.y < th.y) ? 2u : 0u)) << (2u * hh);
+        }
+    }
+    for (;;)
+    {
+        if (pt_ballot(cand != 0u) == 0ull) break;
+#ifdef PT_STAMPS
+        ++q.leafSlotIters; ++q.leafExactIters;
+#endif
+        if (cand != 0u)
+        {
+            const uint32_t k = (uint32_t)__builtin_ctz(cand);
+            cand &= cand - 1u;
+            const float* blk = reinterpret_cast<const float*>(b.sph + 4 * leaf) + k;
+            V3 c = v3(blk[0], blk[4], blk[8]);
+            const float r2 = blk[12];
+            if (MOVING) { const float* vb = reinterpret_cast<const float*>(b.vel + 3 * leaf) + k; c = add(c, mul(v3(vb[0], vb[4], vb[8]), time)); } // main.cpp:66
+            const float t = intersect_sphere_exact(ray, c, r2);
+            if (t > kMinT && t <= best)
+            {
+                // an exact tie between two spheres goes to the lower original index; the indices are fetched only then
+                // (a tie with the plane hit, bestSlot < 0, leaves the plane in place)
+                const uint32_t slot = 4u * leaf + k;
+                bool take = t < best;
+                if (!take && bestSlot >= 0)
+                    take = __float_as_uint(b.mat[2 * slot].w) < __float_as_uint(b.mat[2 * (uint32_t)bestSlot].w);
+                if (take) { best = t; cull = t * kCullSlack; bestSlot = (int32_t)slot; }
+            }
+        }
+    }
+}
+// Scenes of a handful of spheres (MODE_FEW): no tree, no traversal state -- every ray meets every block.
+template <bool MOVING>
+PT_DEV void few_query(const BvhView& b, uint32_t nblocks, const Ray& ray, float time, bool live, QueryCtx& q, float& best, int32_t& bestSlot)
+{
+    float cull = best;
+#pragma nounroll
+    for (uint32_t blk = 0; blk < nblocks; ++blk) block_test<MOVING>(b, blk, live, ray, time, q, best, cull, bestSlot);
+}
+
 // Advances the traversals of the wave.  exitRule = 0: until every lane is done.  Else (pack_exit_rule: minActive |
 // doneMul << 8) the run is also left as soon as fewer than minActive lanes are still traversing AND the live lanes that
 // have finished number more than 4 / doneMul of them (doneMul 4: more finished than traversing) -- the
@@ -748,65 +821,8 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
         const bool atLeaf = (cur & kBvhLeafFlag) && cur != kBvhDone;
         if constexpr (BLK)
         {
-            // the leaf's block: the filter of sphere_clearly_missed over its four slots at once, in packed FP32
-            uint32_t cand = 0;
-            const uint32_t leaf = cur & 0x0FFFu;
-            if (atLeaf)
-            {
-#pragma clang fp contract(fast)
-                q.laneTests += ((cur >> 12) & 3u) + 1u;
-                const f32x2 ox = {ray.o.x, ray.o.x}, oy = {ray.o.y, ray.o.y}, oz = {ray.o.z, ray.o.z};
-                const f32x2 dx = {ray.d.x, ray.d.x}, dy = {ray.d.y, ray.d.y}, dz = {ray.d.z, ray.d.z};
-                const float2* blk2 = reinterpret_cast<const float2*>(b.sph + 4 * leaf);
-                // two slots at a time (a rolled loop: all four at once want more registers than the kernel's budget has)
-#pragma nounroll
-                for (uint32_t hh = 0; hh < 2u; ++hh)
-                {
-                    const float2 X = blk2[hh], Y = blk2[2 + hh], Z = blk2[4 + hh], R = blk2[6 + hh];
-                    f32x2 cx = {X.x, X.y}, cy = {Y.x, Y.y}, cz = {Z.x, Z.y};
-                    if (MOVING)
-                    {
-                        const float2* vb2 = reinterpret_cast<const float2*>(b.vel + 3 * leaf);
-                        const float2 VX = vb2[hh], VY = vb2[2 + hh], VZ = vb2[4 + hh];
-                        const f32x2 tt = {time, time};
-                        cx = f32x2{VX.x, VX.y} * tt + cx; cy = f32x2{VY.x, VY.y} * tt + cy; cz = f32x2{VZ.x, VZ.y} * tt + cz;
-                    }
-                    const f32x2 gx = ox - cx, gy = oy - cy, gz = oz - cz;
-                    const f32x2 hb = gx * dx + gy * dy + gz * dz;
-                    const f32x2 oo = gx * gx + gy * gy + gz * gz;
-                    const f32x2 h2 = hb * hb;
-                    const f32x2 ds = h2 - (oo - f32x2{R.x, R.y});
-                    const f32x2 th = (h2 + oo) * f32x2{-1e-5f, -1e-5f};
-                    // (a NaN -- the stale ray of a lane without a path never gets here -- would make the slot a candidate: safe)
-                    cand |= ((!(ds.x < th.x) ? 1u : 0u) | (!(ds.y < th.y) ? 2u : 0u)) << (2u * hh);
-                }
-            }
-            // the exact (reference-arithmetic) test for what the filter left, one candidate per lane and trip
-            for (;;)
-            {
-                if (pt_ballot(cand != 0u) == 0ull) break;
-#ifdef PT_STAMPS
-                ++q.leafSlotIters; ++q.leafExactIters;
-#endif
-                if (cand != 0u)
-                {
-                    const uint32_t k = (uint32_t)__builtin_ctz(cand);
-                    cand &= cand - 1u;
-                    const float* blk = reinterpret_cast<const float*>(b.sph + 4 * leaf) + k;
-                    V3 c = v3(blk[0], blk[4], blk[8]);
-                    const float r2 = blk[12];
-                    if (MOVING) { const float* vb = reinterpret_cast<const float*>(b.vel + 3 * leaf) + k; c = add(c, mul(v3(vb[0], vb[4], vb[8]), time)); } // main.cpp:66
-                    const float t = intersect_sphere_exact(ray, c, r2);
-                    if (t > kMinT && t <= best)
-                    {
-                        const uint32_t slot = 4u * leaf + k;
-                        bool take = t < best;
-                        if (!take && bestSlot >= 0)
-                            take = __float_as_uint(b.mat[2 * slot].w) < __float_as_uint(b.mat[2 * (uint32_t)bestSlot].w);
-                        if (take) { best = t; cull = t * kCullSlack; bestSlot = (int32_t)slot; }
-                    }
-                }
-            }
+            if (atLeaf) q.laneTests += ((cur >> 12) & 3u) + 1u;
+            block_test<MOVING>(b, cur & 0x0FFFu, atLeaf, ray, time, q, best, cull, bestSlot);
         }
         else
         {
@@ -1029,7 +1045,7 @@ template <bool MOVING, bool BLK = false> PT_DEV V3 trav_centre(const BvhView& b,
 struct Hit { float t; int32_t prim; V3 point, normal; Material m; };
 
 // How the sphere query is answered.
-enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2, MODE_BVH_LDS = 3, MODE_BVH_Q = 4, MODE_REF = 5, MODE_BVH_Q4 = 6 };
+enum : int { MODE_LDS_FAST = 0, MODE_LDS_STRICT = 1, MODE_BVH = 2, MODE_BVH_LDS = 3, MODE_BVH_Q = 4, MODE_REF = 5, MODE_BVH_Q4 = 6, MODE_FEW = 7 };
 constexpr bool mode_is_bvh(int m) { return m == MODE_BVH || m == MODE_BVH_LDS || m == MODE_BVH_Q || m == MODE_BVH_Q4; }
 constexpr bool mode_in_hbm(int m) { return m == MODE_BVH || m == MODE_BVH_Q || m == MODE_BVH_Q4; } // tree read from HBM; BVH_LDS: tree staged in LDS
 // Which traversals test boxes against a cone around the ray (box_hit_cone): all of them.  The cone is what makes the
@@ -1209,6 +1225,17 @@ template <bool MOVING, int MODE> PT_DEV Hit closest_hit(const SceneView& s, cons
         trav_begin<MODE == MODE_BVH_LDS>(q.bvh, planeT, planeIdx, live, q, ts);
         run_traversal<MOVING, MODE>(q.bvh, ray, time, live, q, ts, 0u);
         return make_hit_bvh<MOVING, MODE == MODE_BVH_LDS>(s, ray, time, q, ts);
+    }
+    if (MODE == MODE_FEW)
+    {
+        // a handful of spheres as leaf blocks in LDS (n_spheres = 4 x blocks here): every ray meets every block; a sphere
+        // is recorded only when its t is below the plane's (ties stay with the plane), as in the traversals
+        float best = planeT; int32_t slot = -1;
+        few_query<MOVING>(q.bvh, q.bvh.n_spheres >> 2, ray, time, live, q, best, slot);
+        Material m; m.type = MAT_NONE; m.colour = v4(0, 0, 0, 0); m.roughness = 0; m.n = 0;
+        uint32_t orig = 0;
+        if (slot >= 0) { m = load_material(q.bvh.mat, (uint32_t)slot); orig = __float_as_uint(q.bvh.mat[2 * (uint32_t)slot].w); }
+        return make_hit(s, ray, slot, best, trav_centre<MOVING, true>(q.bvh, slot, time), m, orig, planeIdx, slot >= 0 ? kF32Max : best);
     }
     if (MODE == MODE_REF)
     {

@@ -55,7 +55,7 @@ template <int MODE> __device__ __forceinline__ QueryCtx make_query(const SceneAr
 {
     QueryCtx q;
     q.bvh = a.bvh;
-    if (MODE == MODE_BVH_LDS)
+    if (MODE == MODE_BVH_LDS || MODE == MODE_FEW)
     {
         q.bvh.nodes = smem + a.bvh_off[0]; q.bvh.sph = smem + a.bvh_off[1]; q.bvh.vel = smem + a.bvh_off[2];
         if (a.bvh_off[3] != 0xFFFFFFFFu) q.bvh.mat = smem + a.bvh_off[3]; // else: materials stay in HBM (touched once per hit)
@@ -408,6 +408,7 @@ template <bool MOVING, int MODE, bool CARRY> RenderKernel render_kernel_for(bool
     if constexpr (MODE == MODE_BVH_LDS) return resume ? &k_render_w7<MOVING, MODE, true, CARRY> : &k_render_w7<MOVING, MODE, false, CARRY>;
     else if constexpr (mode_in_hbm(MODE)) return resume ? &k_render_w6<MOVING, MODE, true, CARRY> : &k_render_w6<MOVING, MODE, false, CARRY>;
     else if constexpr (MODE == MODE_LDS_STRICT || MODE == MODE_REF) return &k_render<MOVING, MODE, CARRY>; // test / compatibility modes: left to the compiler
+    else if constexpr (MODE == MODE_FEW) return &k_render_w7<MOVING, MODE, false, CARRY>; // (8 waves per SIMD, <= 64 VGPRs: measured equal)
     else return &k_render_w6<MOVING, MODE, false, CARRY>;
 }
 template <bool MOVING, bool CARRY> RenderKernel render_kernel_mc(int mode, bool resume)
@@ -418,6 +419,7 @@ template <bool MOVING, bool CARRY> RenderKernel render_kernel_mc(int mode, bool 
     if (mode == MODE_BVH_Q4) return render_kernel_for<MOVING, MODE_BVH_Q4, CARRY>(resume);
     if (mode == MODE_LDS_STRICT) return render_kernel_for<MOVING, MODE_LDS_STRICT, CARRY>(resume);
     if (mode == MODE_REF) return render_kernel_for<MOVING, MODE_REF, CARRY>(resume);
+    if (mode == MODE_FEW) return render_kernel_for<MOVING, MODE_FEW, CARRY>(resume);
     return render_kernel_for<MOVING, MODE_LDS_FAST, CARRY>(resume);
 }
 static RenderKernel render_kernel(bool moving, int mode, bool resume, bool carry)
@@ -582,6 +584,7 @@ struct pt_ctx
     float4* blob_dev = nullptr; float4* blob_planes_dev = nullptr; float4* blob_bvh_dev = nullptr; // brute-force image, planes only, planes + tree
     float4* nodes_dev = nullptr; float4* sph_dev = nullptr; float4* vel_dev = nullptr; float4* mat_dev = nullptr;
     float4* mat_lds_dev = nullptr;  // materials in the order of the LDS tree's leaf blocks
+    float4* blob_few_dev = nullptr; float4* mat_few_dev = nullptr; bool few_ok = false; SceneArgs sc_few{}; // MODE_FEW: planes + every sphere as leaf blocks
     uint32_t bvh_nodes = 0, bvh_depth = 0;
     SceneArgs sc_lds{}, sc_bvh{}, sc_bvh_lds{}, sc_ref{};
     pt_scene_desc desc{};                       // the uploaded scene's description: COPIES of the caller's arrays (below), for pt_hip_build_reference_tree
@@ -617,6 +620,7 @@ struct pt_prepared
     std::vector<float> nodes_f;            // the tree read from HBM: 64-byte float nodes ...
     std::vector<uint32_t> nodes_u;         // ... or grid nodes (32-byte 2-wide / 64-byte 4-wide)
     std::vector<float> sph, vel, mat;      // sphere payload in leaf order
+    std::vector<float> few_img, mat_few; bool few_ok = false; SceneArgs sc_few{}; // MODE_FEW (scenes of at most kFewMax spheres)
     std::vector<float> mat_lds;            // the materials once more in the order of the LDS tree's leaf blocks (slot = 4 x leaf + position)
     std::vector<float> bvh_lds_img;        // planes + tree + spheres staged in LDS by the MODE_BVH_LDS kernels
     SceneArgs sc_lds{}, sc_bvh{}, sc_bvh_lds{};
@@ -719,6 +723,7 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
         if (!ctx->lds_ok) return PT_ERR_UNSUPPORTED;
         *mode = (flags & PT_FLAG_STRICT_SEARCH) ? MODE_LDS_STRICT : MODE_LDS_FAST; *sc = &ctx->sc_lds;
     }
+    else if (ctx->few_ok && !(flags & PT_FLAG_FORCE_BVH)) { *mode = MODE_FEW; *sc = &ctx->sc_few; }
     else if (ctx->bvh_lds_ok && !(flags & PT_FLAG_FORCE_BVH)) { *mode = MODE_BVH_LDS; *sc = &ctx->sc_bvh_lds; }
     else
     {
@@ -736,8 +741,8 @@ int select_mode(pt_ctx* ctx, uint32_t flags, uint32_t waves, bool acc, int* mode
     do {                                                                                                        \
         int st_ = PT_OK;                                                                                        \
         auto go_ = [&](auto kern) { st_ = set_lds(ctx, kern, lds); if (st_ == PT_OK) hipLaunchKernelGGL(kern, grid, block, lds, stream, args); }; \
-        if (moving) { if (mode == MODE_BVH_LDS) go_(KERNEL<true, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<true, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<true, MODE_BVH_Q>); else if (mode == MODE_BVH_Q4) go_(KERNEL<true, MODE_BVH_Q4>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<true, MODE_LDS_STRICT>); else if (mode == MODE_REF) go_(KERNEL<true, MODE_REF>); else go_(KERNEL<true, MODE_LDS_FAST>); } \
-        else        { if (mode == MODE_BVH_LDS) go_(KERNEL<false, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<false, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<false, MODE_BVH_Q>); else if (mode == MODE_BVH_Q4) go_(KERNEL<false, MODE_BVH_Q4>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<false, MODE_LDS_STRICT>); else if (mode == MODE_REF) go_(KERNEL<false, MODE_REF>); else go_(KERNEL<false, MODE_LDS_FAST>); } \
+        if (moving) { if (mode == MODE_BVH_LDS) go_(KERNEL<true, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<true, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<true, MODE_BVH_Q>); else if (mode == MODE_BVH_Q4) go_(KERNEL<true, MODE_BVH_Q4>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<true, MODE_LDS_STRICT>); else if (mode == MODE_REF) go_(KERNEL<true, MODE_REF>); else if (mode == MODE_FEW) go_(KERNEL<true, MODE_FEW>); else go_(KERNEL<true, MODE_LDS_FAST>); } \
+        else        { if (mode == MODE_BVH_LDS) go_(KERNEL<false, MODE_BVH_LDS>); else if (mode == MODE_BVH) go_(KERNEL<false, MODE_BVH>); else if (mode == MODE_BVH_Q) go_(KERNEL<false, MODE_BVH_Q>); else if (mode == MODE_BVH_Q4) go_(KERNEL<false, MODE_BVH_Q4>); else if (mode == MODE_LDS_STRICT) go_(KERNEL<false, MODE_LDS_STRICT>); else if (mode == MODE_REF) go_(KERNEL<false, MODE_REF>); else if (mode == MODE_FEW) go_(KERNEL<false, MODE_FEW>); else go_(KERNEL<false, MODE_LDS_FAST>); } \
         if (st_ != PT_OK) return st_;                                                                           \
     } while (0)
 
@@ -749,6 +754,7 @@ constexpr uint32_t kMinChunkSpp = 4;   // never cut a tile's samples finer than 
                                        // resident wave go down to 2
 constexpr uint64_t kTinyFrame = 16;
 constexpr uint32_t kFewSpheres = 16;
+constexpr uint32_t kFewMax = 8;        // up to this many spheres the query is a straight loop over leaf blocks, no tree (MODE_FEW)
 constexpr uint32_t kMaxChunks = 4096;  // (the walk in the kernel is linear in the chunk index)
 constexpr uint64_t kMaxPartialBytes = 4ull << 30; // per-chunk partial images the context may hold (PT_FLAG_REPRODUCIBLE frames only)
 
@@ -777,7 +783,7 @@ struct DevBuf
 
 void free_scene(pt_ctx* c)
 {
-    float4** ptrs[] = {&c->blob_dev, &c->blob_planes_dev, &c->blob_bvh_dev, &c->nodes_dev, &c->sph_dev, &c->vel_dev, &c->mat_dev, &c->mat_lds_dev};
+    float4** ptrs[] = {&c->blob_dev, &c->blob_planes_dev, &c->blob_bvh_dev, &c->nodes_dev, &c->sph_dev, &c->vel_dev, &c->mat_dev, &c->mat_lds_dev, &c->blob_few_dev, &c->mat_few_dev};
     for (float4** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     if (c->ref_nodes_dev) { (void)hipFree(c->ref_nodes_dev); c->ref_nodes_dev = nullptr; }
     c->has_ref = false;
@@ -953,6 +959,34 @@ int prepare_scene(const pt_scene_desc* d, pt_prepared* P)
     }
     else
         P->mat_lds.clear();
+    // (4) a handful of spheres: no tree at all -- planes + every sphere in leaf blocks, every ray meets every block
+    P->few_ok = bv.n_spheres != 0 && bv.n_spheres <= kFewMax && !getenv("PT_NO_FEW");
+    if (P->few_ok)
+    {
+        const uint32_t nb = (bv.n_spheres + 3u) / 4u;
+        std::vector<float> fb(16 * (size_t)nb), fv(bv.moving ? 12 * (size_t)nb : 0, 0.0f);
+        P->mat_few.assign(32 * (size_t)nb, 0.0f);
+        for (uint32_t sl = 0; sl < 4u * nb; ++sl)
+        {
+            const bool real = sl < bv.n_spheres;
+            const float* sp = bv.sph.data() + 4 * (size_t)(real ? sl : 0u);
+            float* blk = fb.data() + 16 * (size_t)(sl >> 2); const uint32_t k = sl & 3u;
+            blk[k] = sp[0]; blk[4 + k] = sp[1]; blk[8 + k] = sp[2]; blk[12 + k] = real ? sp[3] : -1.0e30f;
+            float* m = P->mat_few.data() + 8 * (size_t)sl;
+            if (real) memcpy(m, bv.mat.data() + 8 * (size_t)sl, 32); else m[3] = pth::u2f(0xFFFFFFFFu);
+            if (bv.moving && real) { const float* v = bv.vel.data() + 4 * (size_t)sl; float* vb = fv.data() + 12 * (size_t)(sl >> 2); vb[k] = v[0]; vb[4 + k] = v[1]; vb[8 + k] = v[2]; }
+        }
+        std::vector<float>& img = P->few_img;
+        img.resize(P->blob_planes.f4.size() * 4);
+        if (!img.empty()) memcpy(img.data(), P->blob_planes.f4.data(), img.size() * 4);
+        P->sc_few = P->sc_bvh;
+        P->sc_few.refill_min = refillLds; P->sc_few.carry_max = carryLds; P->sc_few.exit_lanes = 0; P->sc_few.stack_entries = 0;
+        P->sc_few.bvh_off[0] = 0; P->sc_few.bvh_off[3] = 0xFFFFFFFFu;
+        P->sc_few.bvh_off[1] = (uint32_t)(img.size() / 4); img.insert(img.end(), fb.begin(), fb.end());
+        P->sc_few.bvh_off[2] = (uint32_t)(img.size() / 4); img.insert(img.end(), fv.begin(), fv.end());
+        P->sc_few.blob = nullptr; P->sc_few.blob_f4 = (uint32_t)(img.size() / 4);
+        P->sc_few.bvh = BvhView{nullptr, nullptr, nullptr, nullptr, 0u, 4u * nb, {0, 0, 0}, {1, 1, 1}};
+    }
     if (!P->bvh_wide && !P->bvh_q) P->nodes_f.swap(bv.nodes);
     P->sph.swap(bv.sph); P->vel.swap(bv.vel); P->mat.swap(bv.mat);
     return PT_OK;
@@ -995,6 +1029,15 @@ int commit_scene(pt_ctx* ctx, const pt_prepared& P)
         ctx->sc_bvh_lds = P.sc_bvh_lds;
         ctx->sc_bvh_lds.blob = ctx->blob_bvh_dev;
         ctx->sc_bvh_lds.bvh.mat = ctx->mat_lds_dev;
+    }
+    ctx->few_ok = P.few_ok;
+    if (P.few_ok)
+    {
+        st = upload_f4(ctx, P.few_img.data(), P.few_img.size() * 4, &ctx->blob_few_dev); if (st != PT_OK) return st;
+        st = upload_f4(ctx, P.mat_few.data(), P.mat_few.size() * 4, &ctx->mat_few_dev); if (st != PT_OK) return st;
+        ctx->sc_few = P.sc_few;
+        ctx->sc_few.blob = ctx->blob_few_dev;
+        ctx->sc_few.bvh.mat = ctx->mat_few_dev;
     }
     ctx->has_scene = true;
     return PT_OK;
@@ -1322,7 +1365,7 @@ static int render_launch(pt_ctx* ctx, const pt_params* p, float* accum_dev, hipS
     ctx->last_mode = mode;
     ctx->last = pt_stats{};
     ctx->last.samples = (uint64_t)p->width * p->height * a.nspp;
-    ctx->last.kernel = mode_in_hbm(mode) ? 1u : mode == MODE_BVH_LDS ? 3u : mode == MODE_LDS_STRICT ? 2u : mode == MODE_REF ? 4u : 0u;
+    ctx->last.kernel = mode_in_hbm(mode) ? 1u : mode == MODE_BVH_LDS ? 3u : mode == MODE_LDS_STRICT ? 2u : mode == MODE_REF ? 4u : mode == MODE_FEW ? 5u : 0u;
     ctx->last.node_bytes = mode == MODE_BVH_Q ? 32u : mode_is_bvh(mode) ? 64u : 0u;
     ctx->last.node_width = mode == MODE_BVH_Q4 ? 4u : mode_is_bvh(mode) ? 2u : 0u;
     return PT_OK;
@@ -1382,6 +1425,11 @@ int pt_hip_last_stats(pt_ctx* ctx, pt_stats* out)
     {
         ctx->last.node_visits = st[6];   // inner nodes fetched (two box tests each; reference tree: one hit_test each)
         ctx->last.sphere_tests = st[7];  // exact leaf tests
+    }
+    else if (ctx->last_mode == MODE_FEW)
+    {
+        ctx->last.sphere_tests = st[0] * (uint64_t)ctx->desc.n_spheres; // every segment meets every sphere (filter; exact test for the candidates)
+        ctx->last.node_visits = 0;
     }
     else
     {

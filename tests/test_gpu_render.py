@@ -52,8 +52,29 @@ def test_render_default_equals_oracle(renderer, oracle):
         st = renderer.stats()
         ref, seg = oracle.render_philox(oh, w, h, 0, spp, depth, seed=6)
         oracle.scene_free(oh)
+        # (scenes of at most 8 spheres: the straight loop over leaf blocks, no tree)
+        assert st["kernel"] == (5 if sa.n_spheres <= 8 else 3) and st["segments"] == seg, sid
+        assert _close_sums(img, ref, spp), sid
+
+
+def test_small_scenes_through_the_tree_in_lds(renderer, oracle, monkeypatch):
+    """PT_NO_FEW=1 (read at upload): scenes 3 (5 moving spheres: velocity blocks) and 4 (3 spheres: a tree that is one leaf)
+    take the tree-in-LDS kernel they would otherwise skip -- same samples as the oracle, bit-equal per sample."""
+    monkeypatch.setenv("PT_NO_FEW", "1")
+    for sid, w, h, spp, depth in ((3, 64, 36, 8, 50), (4, 48, 27, 8, 50)):
+        sa = builtin_scene_arrays(sid, w / h)
+        renderer.upload(to_pt_scene(sa))
+        oh = oracle.scene(sa)
+        img = renderer.render(w, h, 0, spp, depth, seed=6)
+        st = renderer.stats()
+        ref, seg = oracle.render_philox(oh, w, h, 0, spp, depth, seed=6)
+        pix = np.arange(0, w * h, 5, dtype=np.uint32)
+        c, _ = renderer.probe_samples(w, h, pix, np.full_like(pix, 3), depth, seed=6)
+        co, _ = oracle.samples_philox(oh, w, h, pix, np.full_like(pix, 3), depth, seed=6)
+        oracle.scene_free(oh)
         assert st["kernel"] == 3 and st["segments"] == seg, sid
         assert _close_sums(img, ref, spp), sid
+        assert bit_equal(c, co), sid
 
 
 @pytest.mark.parametrize("flags", [0, pt.FLAG_FORCE_BVH, pt.FLAG_STRICT_SEARCH])

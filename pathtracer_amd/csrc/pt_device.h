@@ -626,13 +626,18 @@ PT_DEV void trav_begin(const BvhView& b, float tLimit, int32_t planeIdx, bool li
 // One leaf block against one ray (lanes with !active ride along): the conservative filter of sphere_clearly_missed over
 // the block's four slots in packed FP32, then the exact (reference-arithmetic) test for the candidates it leaves, one per
 // lane and trip of a wave-uniform loop.  Updates the lane's closest hit (slot = 4 x block + position).
-template <bool MOVING>
+// PACKED: the filter in packed FP32, two slots per instruction.  A packed FMA issues at 0.57 of the plain rate on this chip
+// (1.14x per FLOP) and wants its operands in register pairs, six for the ray alone: it pays where registers are to spare
+// (MODE_FEW, moving spheres: +3.7 %) and costs spills where they are not (the tree kernel: -3.3 % on book-1).
+template <bool MOVING, bool PACKED>
 PT_DEV void block_test(const BvhView& b, uint32_t leaf, bool active, const Ray& ray, float time, QueryCtx& q, float& best, float& cull, int32_t& bestSlot)
 {
     uint32_t cand = 0;
     if (active)
     {
 #pragma clang fp contract(fast)
+        if constexpr (PACKED)
+        {
         const f32x2 ox = {ray.o.x, ray.o.x}, oy = {ray.o.y, ray.o.y}, oz = {ray.o.z, ray.o.z};
         const f32x2 dx = {ray.d.x, ray.d.x}, dy = {ray.d.y, ray.d.y}, dz = {ray.d.z, ray.d.z};
         const float2* blk2 = reinterpret_cast<const float2*>(b.sph + 4 * leaf);
@@ -657,6 +662,24 @@ PT_DEV void block_test(const BvhView& b, uint32_t leaf, bool active, const Ray& 
             const f32x2 th = (h2 + oo) * f32x2{-1e-5f, -1e-5f};
             // (a NaN -- the stale ray of a lane without a path never gets here -- would make the slot a candidate: safe)
             cand |= ((!(ds.x < th.x) ? 1u : 0u) | (!(ds.y < th.y) ? 2u : 0u)) << (2u * hh);
+        }
+        }
+        else
+        {
+        const float4 X = b.sph[4 * leaf], Y = b.sph[4 * leaf + 1], Z = b.sph[4 * leaf + 2], R = b.sph[4 * leaf + 3];
+        float4 VX = X, VY = Y, VZ = Z;
+        if (MOVING) { VX = b.vel[3 * leaf]; VY = b.vel[3 * leaf + 1]; VZ = b.vel[3 * leaf + 2]; }
+        auto slot = [&](float cx, float cy, float cz, float r2, float vx, float vy, float vz) {
+            if (MOVING) { cx = vx * time + cx; cy = vy * time + cy; cz = vz * time + cz; }
+            const float gx = ray.o.x - cx, gy = ray.o.y - cy, gz = ray.o.z - cz;
+            const float hb = gx * ray.d.x + gy * ray.d.y + gz * ray.d.z;
+            const float oo = gx * gx + gy * gy + gz * gz;
+            const float h2 = hb * hb;
+            // (a NaN -- the stale ray of a lane without a path never gets here -- would make the slot a candidate: safe)
+            return !(h2 - (oo - r2) < -1e-5f * (h2 + oo));
+        };
+        cand = (slot(X.x, Y.x, Z.x, R.x, VX.x, VY.x, VZ.x) ? 1u : 0u) | (slot(X.y, Y.y, Z.y, R.y, VX.y, VY.y, VZ.y) ? 2u : 0u) |
+               (slot(X.z, Y.z, Z.z, R.z, VX.z, VY.z, VZ.z) ? 4u : 0u) | (slot(X.w, Y.w, Z.w, R.w, VX.w, VY.w, VZ.w) ? 8u : 0u);
         }
     }
     for (;;)
@@ -693,7 +716,7 @@ PT_DEV void few_query(const BvhView& b, uint32_t nblocks, const Ray& ray, float 
 {
     float cull = best;
 #pragma nounroll
-    for (uint32_t blk = 0; blk < nblocks; ++blk) block_test<MOVING>(b, blk, live, ray, time, q, best, cull, bestSlot);
+    for (uint32_t blk = 0; blk < nblocks; ++blk) block_test<MOVING, true>(b, blk, live, ray, time, q, best, cull, bestSlot);
 }
 
 // Advances the traversals of the wave.  exitRule = 0: until every lane is done.  Else (pack_exit_rule: minActive |
@@ -822,7 +845,7 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
         if constexpr (BLK)
         {
             if (atLeaf) q.laneTests += ((cur >> 12) & 3u) + 1u;
-            block_test<MOVING>(b, cur & 0x0FFFu, atLeaf, ray, time, q, best, cull, bestSlot);
+            block_test<MOVING, false>(b, cur & 0x0FFFu, atLeaf, ray, time, q, best, cull, bestSlot);
         }
         else
         {

@@ -250,7 +250,8 @@ def main():
         step(events[k])
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+    kernel_ms_steps = [a.elapsed_time(b) for a, b in events]
+    kernel_ms = sum(kernel_ms_steps) / max(1, args.steps)
     st = r.stats()  # last launch: samples, segments (S-bar), library's own HIP-event time
 
     if use_dist:
@@ -356,7 +357,7 @@ def main():
             "config": {"workload": f"{'init_test_scene_' + str(args.scene) if args.scene <= 3 else 'build-defined scene ' + str(args.scene)} ({'book-1 final, ' if args.scene == 1 else ''}{scene.n_spheres} spheres + {scene.n_planes} plane) "
                                    f"{w}x{h}, depth {depth}, " + (f"{spp_all} spp total split over {world} GPU(s)" if args.spp_total > 0 else f"{S} spp per GPU = {spp_all} spp total"),
                        "global_samples_per_step": samples_per_step, "parallelism": f"spp-split x{world} + RCCL all-reduce(sum) of the f32 accumulation buffer" + (f" [REHEARSAL: backend {os.environ['PT_BENCH_BACKEND']}, {n_visible} GPU(s) visible]" if use_dist and os.environ.get("PT_BENCH_BACKEND", "nccl") != "nccl" else ""),
-                       "segments_per_sample": round(sbar, 4), "lane_utilisation": round(st["segments"] / (64.0 * max(1, st["wave_iterations"])), 4), "kernel_ms": round(kernel_ms, 3), "lib_kernel_ms_last": round(st["kernel_ms"], 3),
+                       "segments_per_sample": round(sbar, 4), "lane_utilisation": round(st["segments"] / (64.0 * max(1, st["wave_iterations"])), 4), "kernel_ms": round(kernel_ms, 3), "kernel_ms_steps": [round(x, 2) for x in kernel_ms_steps[:16]], "lib_kernel_ms_last": round(st["kernel_ms"], 3),
                        "step": "render -> " + ("all-reduce(sum, f32) -> " if use_dist else "") + "resolve + BGRA pack -> D2H of the packed image (pinned), all inside the timed region",
                        "readback_ms": readback_ms},
             "roofline": roof,

@@ -20,6 +20,7 @@ struct Options
     int scene = 1; uint32_t n5 = 100000; std::string sceneFile, saveScene, out = "output.bmp";
     uint32_t width = 800, height = 450, spp = 32, depth = 5, flags = 0; // the reference's defaults (src/main.cpp:29-42)
     uint64_t seed = 0; int gpus = 1; uint32_t rngSkip = 0;
+    uint32_t pieces = 1;   // > 1: the samples in this many pieces added to the GPUs' resident sums (PT_FLAG_ACCUMULATE), a progress line each
 };
 
 void usage()
@@ -27,9 +28,10 @@ void usage()
     fprintf(stderr,
             "usage: pt_render [--scene 1|2|3|4|5] [--spheres N (scene 5)] [--scene-file FILE] [--save-scene FILE]\n"
             "                 [--width W] [--height H] [--spp S] [--depth D] [--seed N] [--gpus G] [--flags F] [--out FILE.bmp]\n"
-            "                 [--reference-query [--rng-skip N]]\n"
+            "                 [--reference-query [--rng-skip N]] [--pieces N]\n"
             "  scenes 1-3: the reference's init_test_scene_1/2/3; 4: materials + depth of field; 5: N random spheres\n"
-            "  --reference-query: the reference's own BVH (random-axis median split) and pairwise-combine traversal\n");
+            "  --reference-query: the reference's own BVH (random-axis median split) and pairwise-combine traversal\n"
+            "  --pieces N: render the samples in N pieces into sums that stay on the GPUs (progress line per piece)\n");
 }
 
 bool parse(int argc, char** argv, Options* o)
@@ -53,10 +55,11 @@ bool parse(int argc, char** argv, Options* o)
         else if (a == "--flags" && next(&v)) o->flags = (uint32_t)strtoul(v, nullptr, 0);
         else if (a == "--reference-query") o->flags |= PT_FLAG_REFERENCE_QUERY;
         else if (a == "--rng-skip" && next(&v)) o->rngSkip = (uint32_t)strtoul(v, nullptr, 10);
+        else if (a == "--pieces" && next(&v)) o->pieces = (uint32_t)strtoul(v, nullptr, 10);
         else if (a == "--out" && next(&v)) o->out = v;
         else { fprintf(stderr, "pt_render: bad argument '%s'\n", a.c_str()); return false; }
     }
-    return o->width > 0 && o->height > 0 && o->spp > 0 && o->gpus > 0;
+    return o->width > 0 && o->height > 0 && o->spp > 0 && o->gpus > 0 && o->pieces > 0;
 }
 
 double ms_since(std::chrono::steady_clock::time_point t0)
@@ -90,9 +93,13 @@ int main(int argc, char** argv)
     int st = pt_node_create(o.gpus, &node);
     if (st != PT_OK) { fprintf(stderr, "pt_render: cannot set up %d GPU(s): %s\n", o.gpus, pt_hip_strerror(st)); return 1; }
     st = pt_node_upload_scene(node, &d);
-    if (st == PT_OK && (o.flags & PT_FLAG_REFERENCE_QUERY))
-        for (int g = 0; g < o.gpus && st == PT_OK; ++g) st = pt_hip_build_reference_tree(pt_node_ctx(node, g), o.rngSkip);
     if (st != PT_OK) { fprintf(stderr, "pt_render: %s (%s)\n", pt_hip_strerror(st), pt_node_last_error(node)); return 1; }
+    if (o.flags & PT_FLAG_REFERENCE_QUERY)
+        for (int g = 0; g < o.gpus; ++g)
+        {
+            st = pt_hip_build_reference_tree(pt_node_ctx(node, g), o.rngSkip);   // (its error text lives in the context, not the node)
+            if (st != PT_OK) { fprintf(stderr, "pt_render: device %d: %s (%s)\n", g, pt_hip_strerror(st), pt_hip_last_error(pt_node_ctx(node, g))); return 1; }
+        }
     printf("Upload + BVH build on %d GPU(s): %.1f ms\n", o.gpus, ms_since(tUpload));
 
     // ---- the "PathTracing" span (src/main.cpp:412-481): every device renders its slice of the samples, one RCCL
@@ -101,7 +108,24 @@ int main(int argc, char** argv)
     p.width = o.width; p.height = o.height; p.max_depth = o.depth; p.flags = o.flags; p.seed = o.seed; p.spp_begin = 0; p.spp_end = o.spp;
     std::vector<uint32_t> bgra((size_t)o.width * o.height);
     const auto tRender = std::chrono::steady_clock::now();
-    st = pt_node_render(node, &p, nullptr, bgra.data());
+    if (o.pieces > 1)
+    {
+        // the reference prints "Progress" from its pool callback as blocks finish (src/main.cpp:321-332); here a piece of
+        // the samples is what finishes: each is added to the sums resident on the GPUs, the last snapshot is the frame
+        if (o.pieces > o.spp) o.pieces = o.spp;
+        for (uint32_t k = 0; k < o.pieces && st == PT_OK; ++k)
+        {
+            pt_params q = p;
+            q.flags |= PT_FLAG_ACCUMULATE;
+            pt_spp_slice(0, o.spp, o.pieces, k, &q.spp_begin, &q.spp_end);
+            st = pt_node_render(node, &q, nullptr, nullptr);
+            uint64_t done = 0;
+            if (st == PT_OK) st = pt_node_snapshot(node, nullptr, bgra.data(), &done);
+            if (st == PT_OK) printf("Progress: %.2f%% (%llu of %u spp)\n", 100.0 * (double)done / (double)o.spp, (unsigned long long)done, o.spp);
+        }
+    }
+    else
+        st = pt_node_render(node, &p, nullptr, bgra.data());
     const double renderMs = ms_since(tRender);
     if (st != PT_OK) { fprintf(stderr, "pt_render: %s (%s)\n", pt_hip_strerror(st), pt_node_last_error(node)); return 1; }
     uint64_t samples = 0, segments = 0; double kernelMs = 0;
@@ -111,8 +135,10 @@ int main(int argc, char** argv)
         if (pt_hip_last_stats(pt_node_ctx(node, g), &s) != PT_OK) continue;
         samples += s.samples; segments += s.segments; if (s.kernel_ms > kernelMs) kernelMs = s.kernel_ms;
     }
-    printf("PathTracing: Time elapsed: %.3f ms  (%ux%u, %u spp, depth %u: %.1f Msamples/s; kernel %.3f ms, %.3f segments/sample)\n",
-           renderMs, o.width, o.height, o.spp, o.depth, (double)samples / renderMs / 1e3, kernelMs, samples ? (double)segments / (double)samples : 0.0);
+    // (with --pieces the statistics are the last piece's; the rate is over the whole frame)
+    printf("PathTracing: Time elapsed: %.3f ms  (%ux%u, %u spp, depth %u: %.1f Msamples/s; kernel %.3f ms%s, %.3f segments/sample)\n",
+           renderMs, o.width, o.height, o.spp, o.depth, (double)o.width * o.height * o.spp / renderMs / 1e3, kernelMs, o.pieces > 1 ? " (last piece)" : "",
+           samples ? (double)segments / (double)samples : 0.0);
 
     // ---- output (src/main.cpp:487)
     const auto tWrite = std::chrono::steady_clock::now();

@@ -352,6 +352,17 @@ def test_command_line_renderer_matches_the_library(renderer, tmp_path):
     assert out2.read_bytes() == expect
     bad = subprocess.run([exe, "--spp", "0"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 2
+    # --pieces: the samples in 3 pieces added to sums resident on the GPU (PT_FLAG_ACCUMULATE + pt_node_snapshot), a progress
+    # line per piece as the reference prints per block (src/main.cpp:321-332); the frame = the pieces added in sequence
+    out3 = tmp_path / "c.bmp"
+    r3 = subprocess.run([exe, "--scene", "1", "--pieces", "3", "--out", str(out3)] + common, capture_output=True, text=True, timeout=120)
+    assert r3.returncode == 0, r3.stderr
+    assert r3.stdout.count("Progress:") == 3 and "100.00%" in r3.stdout
+    acc = np.zeros((h, w, 4), np.float32)
+    for k in range(3):
+        a, b = pt.spp_slice(0, spp, 3, k)
+        acc = acc + renderer.render(w, h, a, b, depth, seed=seed, flags=pt.FLAG_REPRODUCIBLE)
+    assert out3.read_bytes() == bytes(pt.bmp_header(w, h)) + pt.pack_bgra(pt.resolve(acc, spp)).astype("<u4").tobytes()
 
 
 def test_progressive_accumulation_on_device(renderer):

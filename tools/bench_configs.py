@@ -31,8 +31,18 @@ for name, sid, n, w, h, spp, depth, flags in CASES:
     r.render_device(p, acc.data_ptr(), 0); r.stats()
     r.render_device(p, acc.data_ptr(), 0)
     st = r.stats()
-    print(json.dumps({"case": name, "spheres": scene.n_spheres, "kernel": {0: "lds-brute", 1: "bvh-hbm", 2: "lds-strict", 3: "bvh-lds"}[st["kernel"]], "samples": st["samples"],
+    print(json.dumps({"case": name, "spheres": scene.n_spheres, "kernel": {0: "lds-brute", 1: "bvh-hbm", 2: "lds-strict", 3: "bvh-lds", 4: "reference-tree", 5: "few-spheres loop"}[st["kernel"]], "samples": st["samples"],
                       "kernel_ms": round(st["kernel_ms"], 2), "Msamples/s": round(st["samples"] / st["kernel_ms"] / 1e3, 1),
                       "sbar": round(st["segments"] / st["samples"], 3), "lane_util": round(st["segments"] / 64 / max(1, st["wave_iterations"]), 3),
                       "node_visits/seg": round(st["node_visits"] / max(1, st["segments"]), 1), "sphere_tests/seg": round(st["sphere_tests"] / max(1, st["segments"]), 1),
                       "scene_build_s": round(t1 - t0, 2), "upload_s(bvh build)": round(t2 - t1, 2)}), flush=True)
+
+# the same scene on a node of ONE GPU through pt_node_upload_scene: one host-side prepare (tree built once), one commit
+if not only or any("node" in o for o in only):
+    scene = pt.Scene.builtin(5, 3840 / 2160, 1000000)
+    with pt.Node(1) as node:
+        b0 = pt.tree_build_count(); t0 = time.time()
+        node.upload(scene)
+        t1 = time.time()
+        print(json.dumps({"case": "C5 upload through pt.Node(1) (pt_scene_prepare once + pt_hip_commit_scene)", "spheres": scene.n_spheres,
+                          "upload_s": round(t1 - t0, 3), "tree_builds": pt.tree_build_count() - b0}), flush=True)

@@ -21,7 +21,7 @@ for PMC in \
   "TD_TD_BUSY_sum TD_TC_STALL_sum" \
   "GRBM_GUI_ACTIVE GRBM_COUNT" ; do
   i=$((i+1))
-  timeout -s KILL 300 rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- $CMD > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed: $PMC"; tail -3 $OUT/pmc$i.log; }
+  timeout -s KILL 300 rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- $CMD > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed: $PMC (no further pass in this call)"; tail -3 $OUT/pmc$i.log; exit 1; }
 done
 python3 $ROOT/tools/make_traffic.py $OUT scene5_n1000000_3840x2160_spp16_d50 $TAG || echo "traffic.json not refreshed"
 mkdir -p $ROOT/gpurun_out/profiles_new && cp $ROOT/profiles/traffic.json $ROOT/gpurun_out/profiles_new/traffic.json

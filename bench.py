@@ -185,7 +185,13 @@ def main():
     # PT_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, all-reduce, barrier) with a single rank too -- a
     # rehearsal of the N > 1 plumbing on a one-GPU box; the numbers of such a run are N = 1 numbers.
     use_dist = world > 1 or os.environ.get("PT_BENCH_FORCE_DIST") == "1"
+    stdout_fd = None
     if use_dist:
+        # the communicator libraries print banners on stdout (RCCL's version block, gloo's "connected to N peer ranks"):
+        # stdout is for the ONE JSON line, so everything else this process prints goes to stderr until then
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         # nccl == RCCL on ROCm.  PT_BENCH_BACKEND=gloo: rehearsal of the N > 1 plumbing (launcher, slices, reduce, max over
@@ -368,7 +374,14 @@ def main():
             out["cpu_baseline"]["host"] = host
             out["config"]["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         assert host_img is not None and host_img.shape == (h, w)
-        print(json.dumps(out))
+        if stdout_fd is not None:
+            sys.stdout.flush()
+            os.dup2(stdout_fd, 1)
+            os.close(stdout_fd)
+            stdout_fd = None
+        print(json.dumps(out), flush=True)
+        if use_dist:
+            os.dup2(2, 1)   # (teardown chatter stays off stdout too)
     r.close()
     if use_dist:
         dist.destroy_process_group()

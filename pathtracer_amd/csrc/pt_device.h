@@ -507,7 +507,10 @@ PT_DEV bool box_hit(float lox, float loy, float loz, float hix, float hiy, float
 // Used where the reference's sphere formula works far from its origin (trees in HBM = big scenes): there it reports
 // hits on spheres the ray misses by up to sqrt(45 * 2^-24) / 2 * |o-c| = 8.2e-4 |o-c| (cancellation in b*b - 4c), and a
 // brute-force search in that arithmetic -- the definition of the query -- finds them; the cone makes the tree visit them.
-constexpr float kConeEps = 1.0e-3f;
+#ifndef PT_CONE_EPS
+#define PT_CONE_EPS 1.0e-3f // (timing experiments only: a smaller cone loses the reference formula's phantom hits)
+#endif
+constexpr float kConeEps = PT_CONE_EPS;
 PT_DEV bool cone_flat(float d) { return !(fabsf(d) > kConeEps * 1.001f); } // the cone outgrows this axis
 // lo planes go with (r2, n2), hi planes with (r1, n1); the coordinates are floats (64-byte nodes) or grid cells (grid
 // nodes, whose grid is folded into the pairs).

@@ -107,3 +107,39 @@ def test_node_progressive_pieces_and_snapshots(renderer, monkeypatch, force_coll
         node.render(w, h, 0, 2, depth, seed=seed)
         with pytest.raises(pt.PtError):
             node.snapshot(w, h)
+
+
+@pytest.mark.parametrize("name,sid,n5,w,h,spp,depth", [
+    ("C3_book1_1080p_4096spp", 1, 0, 1920, 1080, 4096, 50),
+    ("C4_motion_blur_4k_1024spp", 3, 0, 3840, 2160, 1024, 50),
+    ("C5_1e6_spheres_4k_1024spp", 5, 1000000, 3840, 2160, 1024, 50),
+])
+def test_full_size_configs_by_properties(renderer, name, sid, n5, w, h, spp, depth):
+    """BASELINE.json's configurations at their FULL sizes (8.5 G samples each; the oracle cannot follow there), through
+    properties that do not depend on size: every sample exactly once (alpha of every returned colour is 1, and sums of
+    ones are exact in f32 up to 2^24: the alpha plane must equal spp everywhere), the frame in one piece == the 8 per-GPU
+    slices of SURVEY.md 8(e) accumulated into one buffer (same sample set, float summation order apart), no NaN / negative
+    sums, and the statistics the roofline uses are those of the sample count."""
+    torch = pytest.importorskip("torch")
+    renderer.upload(pt.Scene.builtin(sid, w / h, n5))
+    stream = torch.cuda.current_stream().cuda_stream
+    whole = torch.empty((h, w, 4), dtype=torch.float32, device="cuda:0")
+    renderer.render_device(renderer.params(w, h, 0, spp, depth, seed=2), whole.data_ptr(), stream)
+    torch.cuda.synchronize()
+    st = renderer.stats()
+    assert st["samples"] == w * h * spp and st["segments"] >= st["samples"]
+    assert bool((whole[..., 3] == float(spp)).all()), name
+    assert bool(torch.isfinite(whole).all()) and float(whole.min()) >= 0.0
+    pieces = torch.zeros_like(whole)
+    segs = 0
+    for g in range(8):
+        a, b = pt.spp_slice(0, spp, 8, g)
+        renderer.render_device(renderer.params(w, h, a, b, depth, seed=2, flags=pt.FLAG_ACCUMULATE), pieces.data_ptr(), stream)
+        torch.cuda.synchronize()
+        segs += renderer.stats()["segments"]
+    assert segs == st["segments"], name                        # the same paths, segment for segment
+    assert bool((pieces[..., 3] == float(spp)).all()), name
+    rel = float(((pieces[..., :3] - whole[..., :3]).abs() / whole[..., :3].abs().clamp_min(1.0)).max())
+    assert rel <= 64 * 2.0 ** -24 * 8, (name, rel)             # summation order only
+    print(f"{name}: {st['samples'] / 1e9:.2f} G samples in {st['kernel_ms']:.0f} ms = {st['samples'] / st['kernel_ms'] / 1e3:.0f} Msamples/s; "
+          f"one piece vs 8 accumulated slices: max rel diff {rel:.2e}")

@@ -1385,8 +1385,12 @@ template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray
         float refractRatio = 1.0f / h.m.n;
         if (dot(ray.d, h.normal) > 0.0f) refractRatio = 1.0f / refractRatio;
         float cosTheta = dot(neg(ray.d), h.normal);
-        float sinTheta = sqrtf(1 - cosTheta * cosTheta);
-        bool internalReflection = refractRatio * sinTheta > 1.0f;
+        // refractRatio * sqrtf(1 - cos^2) > 1.0f (main.cpp:272-273) can only hold for a ratio above 1: the root of a value
+        // <= 1 is <= 1 (a negative argument gives NaN, which compares false), and the rounded product of two floats <= 1
+        // is <= 1 -- so the correctly rounded root (~17 instructions) is only formed for lanes that leave the denser
+        // medium (in the reference's scenes: hits on the glass floor of scene 2 from below)
+        bool internalReflection = false;
+        if (refractRatio > 1.0f) internalReflection = refractRatio * sqrtf(1 - cosTheta * cosTheta) > 1.0f;
         bool shouldReflect = reflectance((double)cosTheta, (double)refractRatio) > xi;
         if (internalReflection || shouldReflect)
             raw = reflect_direction(ray.d, h.normal);

@@ -56,7 +56,7 @@ SANDIR := tests/native/build
 asan: $(SANDIR)/host_sanitize
 $(SANDIR)/host_sanitize: tests/native/host_sanitize.cpp $(HOST)/pt_world.cpp $(HOST)/pt_world.h $(CSRC)/pt_bvh.h $(CSRC)/pt_guard.h include/pt_hip.h
 	@mkdir -p $(SANDIR)
-	g++ -O1 -g -std=c++17 -Wall -ffp-contract=off -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer tests/native/host_sanitize.cpp $(HOST)/pt_world.cpp -o $@ -pthread
+	g++ -O1 -g -std=c++17 -Wall -ffp-contract=off -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -static-libasan -static-libubsan tests/native/host_sanitize.cpp $(HOST)/pt_world.cpp -o $@ -pthread
 oom: $(SANDIR)/host_oom
 $(SANDIR)/host_oom: tests/native/host_oom.cpp include/pt_hip.h $(LIBDIR)/libpt_hip.so
 	@mkdir -p $(SANDIR)

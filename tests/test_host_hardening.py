@@ -21,8 +21,9 @@ def test_host_passes_under_asan_ubsan(tmp_path):
     """pt_world.cpp + pt_bvh.h (scene builders, scene-file parser on malformed files, both tree builders, the widening with
     leaves of up to 8 spheres) under -fsanitize=address,undefined."""
     _make("asan")
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
-    env.pop("LD_PRELOAD", None)  # (ASan wants to be the first library in the process)
+    # (the sanitizer runtime is linked statically and told not to insist on being the first library of the process: the
+    # environment's own preloads stay as they are)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:verify_asan_link_order=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     r = subprocess.run([os.path.join(BUILD, "host_sanitize"), str(tmp_path)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
     assert "all checks held" in r.stderr

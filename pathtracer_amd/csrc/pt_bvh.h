@@ -105,6 +105,12 @@ inline void build_bvh(const pt_scene_desc* d, BvhData* out)
     constexpr int NB = 16;
     unsigned nthreads = ptg::host_threads(16); // (affinity mask and cgroup quota respected; a thread that cannot start runs inline)
     if (n < 65536) nthreads = 1;
+    // ranges of up to sweepMax spheres get the exact SAH sweep instead of the bins (below) -- in scenes small enough that
+    // the three sorts per node do not show in the upload (book-1: 7.06 -> 6.82 node visits per segment, +0.7 %; a 10^6-sphere
+    // build keeps its bins all the way down)
+    uint32_t sweepMax = n <= 8192u ? 512u : 0u; bool sweepQuant = false;
+    if (const char* e = getenv("PT_SAH_SWEEP")) { int v = atoi(e); if (v >= 0) sweepMax = (uint32_t)v; }   // tuning experiments only
+    if (const char* e = getenv("PT_SAH_QUANT")) sweepQuant = atoi(e) != 0;                                  // (leaves priced per block: fewer nodes, more leaf visits, -3.5 %)
     out->nodes.clear();
     out->depth = 0;
     auto make_leaf_ref = [](uint32_t begin, uint32_t count) { return kLeafFlag | ((count - 1u) << 28) | begin; };
@@ -170,7 +176,36 @@ inline void build_bvh(const pt_scene_desc* d, BvhData* out)
             }
         }
         uint32_t mid = t.begin; // (stays there when all centroids coincide)
-        if (bestAxis >= 0)
+        // Small ranges of small scenes: the exact SAH sweep instead of the bins -- every split position of the range sorted
+        // by centroid, on each axis.  (PT_SAH_QUANT prices a child by the leaf blocks it will need instead of its spheres.)
+        bool swept = false;
+        if (count <= sweepMax && workers <= 1)
+        {
+            std::vector<uint32_t> order(idx.begin() + t.begin, idx.begin() + t.end), bestOrder;
+            std::vector<float> rightArea(count + 1);
+            float sweepCost = 3e38f; uint32_t sweepAt = 0;
+            auto price = [&](uint32_t c) { return sweepQuant ? (float)((c + kLeafMax - 1) / kLeafMax) : (float)c; };
+            for (int k = 0; k < 3; ++k)
+            {
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b2) { return cen[3 * (size_t)a + k] < cen[3 * (size_t)b2 + k]; });
+                Aabb acc; aabb_reset(acc);
+                for (uint32_t i = count; i-- > 0;) { aabb_grow(acc, box[order[i]]); rightArea[i] = aabb_area(acc); }
+                aabb_reset(acc);
+                for (uint32_t i = 1; i < count; ++i)
+                {
+                    aabb_grow(acc, box[order[i - 1]]);
+                    const float cost = aabb_area(acc) * price(i) + rightArea[i] * price(count - i);
+                    if (cost < sweepCost) { sweepCost = cost; sweepAt = i; bestOrder = order; }
+                }
+            }
+            if (sweepAt != 0)
+            {
+                std::copy(bestOrder.begin(), bestOrder.end(), idx.begin() + t.begin);
+                mid = t.begin + sweepAt;
+                swept = true;
+            }
+        }
+        if (!swept && bestAxis >= 0)
         {
             const int k = bestAxis;
             uint32_t* m = std::partition(idx.data() + t.begin, idx.data() + t.end, [&](uint32_t i) { return bin_of(i, k) <= bestBin; });

@@ -269,6 +269,13 @@ def test_resolve_and_pack_on_device(renderer, oracle):
     assert (bgra_h.reshape(-1) == oracle.pack_bgra(px_h)).all()                    # file_io.h:29-45
     assert (bgra_h.reshape(-1) == pt.pack_bgra(px_h)).all()
     assert ((bgra_h >> 24) >= 254).all()                                           # alpha channel survives
+    # both outputs straight into pinned host memory (what bench.py's step does): the same bits, no copy call
+    px_pin = torch.zeros((h, w, 4), dtype=torch.float32, pin_memory=True)
+    bgra_pin = torch.zeros((h, w), dtype=torch.int32, pin_memory=True)
+    renderer.resolve_device(acc.data_ptr(), w * h, spp, px_pin.data_ptr(), bgra_pin.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert bit_equal(px_pin.numpy(), px_h)
+    assert (bgra_pin.numpy().view(np.uint32) == bgra_h).all()
 
 
 # ---------------------------------------------------------------------------------------------- full-size properties

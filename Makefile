@@ -7,8 +7,12 @@ CSRC     := pathtracer_amd/csrc
 HOST     := pathtracer_amd/host
 # -ffp-contract=off: value-carrying arithmetic keeps the reference's rounding; the sphere search re-enables
 # contraction locally with `#pragma clang fp contract(fast)` (pt_device.h).
+# -fno-slp-vectorize: the SLP vectoriser pairs independent scalar FP32 operations into v_pk_* instructions, which issue at
+# half the plain rate on gfx950 and want their operands in register pairs (moves, spills): book-1 +7.2 % without it
+# (81.1 -> 75.7 ms, 19 -> 14 spilled VGPRs), C2 / C4 scenes +4.6 / +2.4 %.  Packed arithmetic stays where it is written out
+# by hand and measured to pay (the few-sphere loop's filter, the brute-force search).
 # -amdgpu-sched-strategy=max-ilp: +1 % on the bench kernel against the default strategy (tools/ab.py), none of the others measured better
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-sched-strategy=max-ilp -Wall -Wno-unused-function
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp -Wall -Wno-unused-function
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Wall
 
 BINDIR   := pathtracer_amd/bin

@@ -481,9 +481,9 @@ PT_DEV bool sphere_clearly_missed(const Ray& ray, V3 c, float r2)
     const float ox = ray.o.x - c.x, oy = ray.o.y - c.y, oz = ray.o.z - c.z;
     const float hb = ox * ray.d.x + oy * ray.d.y + oz * ray.d.z;
     const float oo = ox * ox + oy * oy + oz * oz;
-    const float disc = hb * hb - (oo - r2);
-    // rounding of either evaluation is bounded by a few ulp of the terms that cancel (hb^2 and |oc|^2)
-    return disc < -1e-5f * (hb * hb + oo);
+    // discriminant hb^2 - (oo - r2) clearly negative: below -1e-5 (hb^2 + oo) -- the rounding of either evaluation, the
+    // reference's and this one, is bounded by a few ulp of the terms that cancel (hb^2 and |oc|^2).  As two FMAs:
+    return (hb * hb) * 1.00001f + r2 < oo * 0.99999f;
 }
 
 // Slab test of one child box against the ray segment [0, best]; contracted arithmetic (boxes are padded by the builder).
@@ -627,48 +627,19 @@ PT_DEV void trav_begin(const BvhView& b, float tLimit, int32_t planeIdx, bool li
 }
 
 // One leaf block against one ray (lanes with !active ride along): the conservative filter of sphere_clearly_missed over
-// the block's four slots in packed FP32, then the exact (reference-arithmetic) test for the candidates it leaves, one per
-// lane and trip of a wave-uniform loop.  Updates the lane's closest hit (slot = 4 x block + position).
-// PACKED: the filter in packed FP32, two slots per instruction.  A packed FMA issues at 0.57 of the plain rate on this chip
-// (1.14x per FLOP) and wants its operands in register pairs, six for the ray alone: it pays where registers are to spare
-// (MODE_FEW, moving spheres: +3.7 %) and costs spills where they are not (the tree kernel: -3.3 % on book-1).
-template <bool MOVING, bool PACKED>
+// the block's four slots, then the exact (reference-arithmetic) test for the candidates it leaves, one per lane and trip
+// of a wave-uniform loop.  Updates the lane's closest hit (slot = 4 x block + position).
+// The filter is plain FP32, one slot after the other.  Packed FP32 (two slots per v_pk_* instruction) was built and
+// measured twice: a packed FMA issues at half the plain rate on this chip and wants its operands in register pairs -- the
+// tree kernel lost 3.3 % to the spills, and once the build stopped the compiler from pairing scalar work on its own
+// (-fno-slp-vectorize, Makefile) the plain filter also won in the few-sphere loop (+6.5 / +10.5 % on the C2 / C4 scenes).
+template <bool MOVING>
 PT_DEV void block_test(const BvhView& b, uint32_t leaf, bool active, const Ray& ray, float time, QueryCtx& q, float& best, float& cull, int32_t& bestSlot)
 {
     uint32_t cand = 0;
     if (active)
     {
 #pragma clang fp contract(fast)
-        if constexpr (PACKED)
-        {
-        const f32x2 ox = {ray.o.x, ray.o.x}, oy = {ray.o.y, ray.o.y}, oz = {ray.o.z, ray.o.z};
-        const f32x2 dx = {ray.d.x, ray.d.x}, dy = {ray.d.y, ray.d.y}, dz = {ray.d.z, ray.d.z};
-        const float2* blk2 = reinterpret_cast<const float2*>(b.sph + 4 * leaf);
-        // two slots at a time (a rolled loop: all four at once want more registers than the kernel's budget has)
-#pragma nounroll
-        for (uint32_t hh = 0; hh < 2u; ++hh)
-        {
-            const float2 X = blk2[hh], Y = blk2[2 + hh], Z = blk2[4 + hh], R = blk2[6 + hh];
-            f32x2 cx = {X.x, X.y}, cy = {Y.x, Y.y}, cz = {Z.x, Z.y};
-            if (MOVING)
-            {
-                const float2* vb2 = reinterpret_cast<const float2*>(b.vel + 3 * leaf);
-                const float2 VX = vb2[hh], VY = vb2[2 + hh], VZ = vb2[4 + hh];
-                const f32x2 tt = {time, time};
-                cx = f32x2{VX.x, VX.y} * tt + cx; cy = f32x2{VY.x, VY.y} * tt + cy; cz = f32x2{VZ.x, VZ.y} * tt + cz;
-            }
-            const f32x2 gx = ox - cx, gy = oy - cy, gz = oz - cz;
-            const f32x2 hb = gx * dx + gy * dy + gz * dz;
-            const f32x2 oo = gx * gx + gy * gy + gz * gz;
-            const f32x2 h2 = hb * hb;
-            const f32x2 ds = h2 - (oo - f32x2{R.x, R.y});
-            const f32x2 th = (h2 + oo) * f32x2{-1e-5f, -1e-5f};
-            // (a NaN -- the stale ray of a lane without a path never gets here -- would make the slot a candidate: safe)
-            cand |= ((!(ds.x < th.x) ? 1u : 0u) | (!(ds.y < th.y) ? 2u : 0u)) << (2u * hh);
-        }
-        }
-        else
-        {
         const float4 X = b.sph[4 * leaf], Y = b.sph[4 * leaf + 1], Z = b.sph[4 * leaf + 2], R = b.sph[4 * leaf + 3];
         float4 VX = X, VY = Y, VZ = Z;
         if (MOVING) { VX = b.vel[3 * leaf]; VY = b.vel[3 * leaf + 1]; VZ = b.vel[3 * leaf + 2]; }
@@ -678,12 +649,12 @@ PT_DEV void block_test(const BvhView& b, uint32_t leaf, bool active, const Ray& 
             const float hb = gx * ray.d.x + gy * ray.d.y + gz * ray.d.z;
             const float oo = gx * gx + gy * gy + gz * gz;
             const float h2 = hb * hb;
+            // clearly missed:  h2 - (oo - r2) < -1e-5 (h2 + oo),  as two FMAs:  (1 + 1e-5) h2 + r2 < (1 - 1e-5) oo
             // (a NaN -- the stale ray of a lane without a path never gets here -- would make the slot a candidate: safe)
-            return !(h2 - (oo - r2) < -1e-5f * (h2 + oo));
+            return !(h2 * 1.00001f + r2 < oo * 0.99999f);
         };
         cand = (slot(X.x, Y.x, Z.x, R.x, VX.x, VY.x, VZ.x) ? 1u : 0u) | (slot(X.y, Y.y, Z.y, R.y, VX.y, VY.y, VZ.y) ? 2u : 0u) |
                (slot(X.z, Y.z, Z.z, R.z, VX.z, VY.z, VZ.z) ? 4u : 0u) | (slot(X.w, Y.w, Z.w, R.w, VX.w, VY.w, VZ.w) ? 8u : 0u);
-        }
     }
     for (;;)
     {
@@ -719,7 +690,7 @@ PT_DEV void few_query(const BvhView& b, uint32_t nblocks, const Ray& ray, float 
 {
     float cull = best;
 #pragma nounroll
-    for (uint32_t blk = 0; blk < nblocks; ++blk) block_test<MOVING, true>(b, blk, live, ray, time, q, best, cull, bestSlot);
+    for (uint32_t blk = 0; blk < nblocks; ++blk) block_test<MOVING>(b, blk, live, ray, time, q, best, cull, bestSlot);
 }
 
 // Advances the traversals of the wave.  exitRule = 0: until every lane is done.  Else (pack_exit_rule: minActive |
@@ -848,7 +819,7 @@ PT_DEV void bvh_run(const BvhView& b, const Ray& ray, float time, bool live, Que
         if constexpr (BLK)
         {
             if (atLeaf) q.laneTests += ((cur >> 12) & 3u) + 1u;
-            block_test<MOVING, false>(b, cur & 0x0FFFu, atLeaf, ray, time, q, best, cull, bestSlot);
+            block_test<MOVING>(b, cur & 0x0FFFu, atLeaf, ray, time, q, best, cull, bestSlot);
         }
         else
         {

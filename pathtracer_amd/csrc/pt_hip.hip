@@ -395,8 +395,9 @@ template <bool MOVING, int MODE, bool CARRY> __global__ void __launch_bounds__(5
 #define PT_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
 #ifndef PT_HBM_WAVES
-#define PT_HBM_WAVES 6 // experiments: make variant DEFS=-DPT_HBM_WAVES=7
+#define PT_HBM_WAVES 7 // (6 until round 3: C5 1 675 -> 1 705 Msamples/s with 8 stack levels in LDS, scene 2 +1 %)  experiments: make variant DEFS=-DPT_HBM_WAVES=6
 #endif
+// (the name is historical: these kernels ran 6 waves per SIMD until round 3)
 template <bool MOVING, int MODE, bool RESUME, bool CARRY> __global__ void __launch_bounds__(512) PT_EU(PT_HBM_WAVES) k_render_w6(RenderArgs a) { render_body<MOVING, MODE, RESUME, CARRY>(a); }
 #ifndef PT_LDS_WAVES
 #define PT_LDS_WAVES 7 // experiments: make variant DEFS=-DPT_LDS_WAVES=6
@@ -659,7 +660,7 @@ constexpr uint32_t kMinResidentWaves = 16; // per CU: below this the LDS-residen
 // from 6 to 12; 10^6 spheres 4K: 431 -> 594 -> 669 -> 700 Msamples/s with 0, 8, 16, 24); a single-leaf tree (up to 4 spheres) has no stragglers and skips it.
 constexpr uint32_t kExitLanes = 10, kExitLanesHbm = 24, kResumeMinSpheres = 4; // (tree in LDS: 8 until the joint sweep at the end of round 2; 10 with leaf batch 20: +0.2-0.5 % at 64-512 spp, C1 +5 %)
 constexpr uint32_t kGridNodeMinSpheres = 32768; // from here on the tree in HBM uses grid nodes (4-wide)
-constexpr uint32_t kWideStackLds = 16;          // 4-wide traversal: stack levels kept in LDS, deeper ones in per-lane scratch (C5, 37 levels needed: 10-20 in LDS 1297-1303 Msamples/s, 24: 1233 -- fewer resident waves)
+constexpr uint32_t kWideStackLds = 8;           // 4-wide traversal: stack levels kept in LDS, deeper ones in per-lane scratch (C5, 37 levels needed; round 3, 7 waves per SIMD: 8 levels 1 705 Msamples/s, 16: 1 628; round 2, 6 waves: 10-20 levels equal, 24 slower -- fewer resident waves)
 // Lanes that must be out of work before the wave runs the refill code (render_body).  Scene in LDS: flat from 20 to 36 on
 // book-1, +2-4 % at 28-36 on the small scenes; tree in HBM (trips dear, refill cheap by comparison): 12.
 constexpr uint32_t kRefillMin = 28, kRefillMinHbm = 12;

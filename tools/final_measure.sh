@@ -8,6 +8,8 @@ mkdir -p $OUT
 cd $ROOT
 timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > $OUT/gpu_tests.log 2>&1 || { tail -5 $OUT/gpu_tests.log; exit 1; }
 tail -1 $OUT/gpu_tests.log
+# BASELINE.json's C3 / C4 / C5 at their full sizes (the test prints one line per configuration)
+timeout -k 10 300 python -u -m pytest tests/test_progressive.py -m gpu -x -q -s -k full_size --timeout 200 --timeout-method thread 2>&1 | grep -oE "C[0-9]_[a-z0-9_]+: .*" > $OUT/full_size.txt || { echo "full-size test failed"; exit 1; }
 # the bench lines FIRST, on a box that has not yet run forty profiler passes (the same build measured 3 % slower behind them)
 timeout -k 10 300 python bench.py --scene 4 --spp-per-gpu 256 --steps 20 --warmup 5 > $OUT/c2_bench.json 2> $OUT/c2_bench.err || { tail -3 $OUT/c2_bench.err; exit 1; }
 timeout -k 10 300 python bench.py --scene 3 --width 3840 --height 2160 --spp-per-gpu 128 --steps 20 --warmup 5 > $OUT/c4_bench.json 2> $OUT/c4_bench.err || { tail -3 $OUT/c4_bench.err; exit 1; }

@@ -660,7 +660,7 @@ constexpr uint32_t kMinResidentWaves = 16; // per CU: below this the LDS-residen
 // from 6 to 12; 10^6 spheres 4K: 431 -> 594 -> 669 -> 700 Msamples/s with 0, 8, 16, 24); a single-leaf tree (up to 4 spheres) has no stragglers and skips it.
 constexpr uint32_t kExitLanes = 10, kExitLanesHbm = 24, kResumeMinSpheres = 4; // (tree in LDS: 8 until the joint sweep at the end of round 2; 10 with leaf batch 20: +0.2-0.5 % at 64-512 spp, C1 +5 %)
 constexpr uint32_t kGridNodeMinSpheres = 32768; // from here on the tree in HBM uses grid nodes (4-wide)
-constexpr uint32_t kWideStackLds = 8;           // 4-wide traversal: stack levels kept in LDS, deeper ones in per-lane scratch (C5, 37 levels needed; round 3, 7 waves per SIMD: 8 levels 1 705 Msamples/s, 16: 1 628; round 2, 6 waves: 10-20 levels equal, 24 slower -- fewer resident waves)
+constexpr uint32_t kWideStackLds = 12;          // 4-wide traversal: stack levels kept in LDS, deeper ones in per-lane scratch (C5, 37 levels needed; round 3, 7 waves per SIMD: 6 / 8 / 10 / 12 / 16 levels 1 656 / 1 703 / 1 716 / 1 721 / 1 628 Msamples/s; round 2, 6 waves: 10-20 levels equal, 24 slower -- fewer resident waves)
 // Lanes that must be out of work before the wave runs the refill code (render_body).  Scene in LDS: flat from 20 to 36 on
 // book-1, +2-4 % at 28-36 on the small scenes; tree in HBM (trips dear, refill cheap by comparison): 12.
 constexpr uint32_t kRefillMin = 28, kRefillMinHbm = 12;

@@ -1176,15 +1176,19 @@ PT_DEV float closest_plane(const SceneView& s, const Ray& ray, int32_t* planeIdx
     return tBest;
 }
 // the hit record (main.cpp:204-216) from the winners of the two searches: sphere `obj` at t (-1: none) and plane planeIdx at planeT
+// On a miss (prim == kPrimMiss; t = planeT, the caller's limit) point, normal and material are left as they come:
+// shade_step reads none of them (main.cpp:219 looks at t alone), and the probe kernel blanks them for its records.
+// (Zeroed "just in case" they were thirteen moves per shading phase.)
 PT_DEV Hit make_hit(const SceneView& s, const Ray& ray, int32_t obj, float t, V3 centre, const Material& sphereMat, uint32_t origIndex, int32_t planeIdx, float planeT)
 {
     Hit h;
-    h.t = planeT; h.prim = kPrimMiss; h.point = v3(0, 0, 0); h.normal = v3(0, 0, 0);
-    h.m.type = MAT_NONE; h.m.colour = v4(0, 0, 0, 0); h.m.roughness = 0; h.m.n = 0;
-    if (obj >= 0 && t > kMinT && t < h.t)
+    const bool sphere = obj >= 0 && t > kMinT && t < planeT;
+    h.t = sphere ? t : planeT;
+    h.prim = kPrimMiss;
+    h.point = ray_at(ray, h.t);
+    if (sphere)
     {
-        h.t = t; h.prim = (int32_t)origIndex;
-        h.point = ray_at(ray, t);
+        h.prim = (int32_t)origIndex;
         h.normal = normalize(sub(h.point, centre));
         h.m = sphereMat;
     }
@@ -1192,19 +1196,16 @@ PT_DEV Hit make_hit(const SceneView& s, const Ray& ray, int32_t obj, float t, V3
     {
         float4 p = s.planes[planeIdx];
         h.prim = -1 - planeIdx;
-        h.point = ray_at(ray, h.t);
         h.normal = v3(p.x, p.y, p.z);
         h.m = load_material(s.pmat, (uint32_t)planeIdx);
     }
     return h;
 }
-// ... for the BVH kernels: from a finished traversal (best = the plane's t unless a sphere beat it)
 template <bool MOVING, bool BLK = false> PT_DEV Hit make_hit_bvh(const SceneView& s, const Ray& ray, float time, const QueryCtx& q, const TravState& ts)
 {
     const int32_t planeIdx = trav_plane(ts.pk);
     const int32_t obj = ts.bestSlot;
-    Material sphereMat; sphereMat.type = MAT_NONE; sphereMat.colour = v4(0, 0, 0, 0); sphereMat.roughness = 0; sphereMat.n = 0;
-    uint32_t origIndex = 0;
+    Material sphereMat; uint32_t origIndex = 0;   // (read by make_hit only with obj >= 0)
     if (obj >= 0) { sphereMat = load_material(q.bvh.mat, (uint32_t)obj); origIndex = __float_as_uint(q.bvh.mat[2 * (uint32_t)obj].w); }
     // a sphere is recorded only when its t is below the plane's (ties stay with the plane), so with obj >= 0 the plane's
     // t is anything above ts.best, and without it ts.best still is the plane's t

@@ -444,6 +444,7 @@ template <bool MOVING, int MODE> __global__ void __launch_bounds__(256) k_probe_
     Ray r; r.o = v3(a.rays[6*i], a.rays[6*i+1], a.rays[6*i+2]); r.d = v3(a.rays[6*i+3], a.rays[6*i+4], a.rays[6*i+5]);
     Hit h = closest_hit<MOVING, MODE>(s, r, a.times[i], true, qc);
     a.t[i] = h.t; a.prim[i] = h.prim;
+    if (h.prim == kPrimMiss) { h.point = v3(0, 0, 0); h.normal = v3(0, 0, 0); }   // (make_hit leaves them undefined on a miss)
     a.point[3*i] = h.point.x; a.point[3*i+1] = h.point.y; a.point[3*i+2] = h.point.z;
     a.normal[3*i] = h.normal.x; a.normal[3*i+1] = h.normal.y; a.normal[3*i+2] = h.normal.z;
 }

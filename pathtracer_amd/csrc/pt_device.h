@@ -1019,7 +1019,7 @@ PT_DEV void bvh_run_wide(const BvhView& b, const Ray& ray, float time, bool live
 // The winner's centre, as the leaf test saw it.
 template <bool MOVING, bool BLK = false> PT_DEV V3 trav_centre(const BvhView& b, int32_t slot, float time)
 {
-    V3 centre = v3(0, 0, 0);
+    V3 centre;   // (slot < 0: undefined, and make_hit does not read it)
     if (BLK)
     {
         if (slot >= 0)   // slot = 4 x leaf + position: component `position` of the leaf's block
@@ -1329,12 +1329,12 @@ template <class R> PT_DEV bool scatter(const Ray& ray, const Hit& h, R& rng, Ray
     // Diffuse and rough metal both start from random_point_in_unit_sphere (utils.h:80-94): one rejection loop for
     // both, so a wave pays max(attempts) once, not once per material branch.  Per lane the draws are unchanged.
     const bool roughMetal = h.m.type == MAT_METAL && h.m.roughness > 0.0f;
-    V3 unitPoint = v3(0, 0, 0);
+    V3 unitPoint;   // (set and read for diffuse and rough metal only)
     bool found = true;
     if (h.m.type == MAT_DIFFUSE || roughMetal) unitPoint = random_point_in_unit_sphere_bounded(rng, maxAttempts, &found);
     // Every material ends in `normalize(new direction)` (main.cpp:231, 251, 293): the branches below only pick the raw
     // direction, the normalisation -- an exact sqrt and three exact divides -- is issued once for the whole wave.
-    V3 raw = v3(0, 0, 0);
+    V3 raw;         // (every material that returns below sets it)
     bool lives = true;
     if (h.m.type == MAT_DIFFUSE)                                         // main.cpp:223-234
     {

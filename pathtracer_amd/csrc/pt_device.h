@@ -671,16 +671,14 @@ PT_DEV void block_test(const BvhView& b, uint32_t leaf, bool active, const Ray& 
             const float r2 = blk[12];
             if (MOVING) { const float* vb = reinterpret_cast<const float*>(b.vel + 3 * leaf) + k; c = add(c, mul(v3(vb[0], vb[4], vb[8]), time)); } // main.cpp:66
             const float t = intersect_sphere_exact(ray, c, r2);
-            if (t > kMinT && t <= best)
-            {
-                // an exact tie between two spheres goes to the lower original index; the indices are fetched only then
-                // (a tie with the plane hit, bestSlot < 0, leaves the plane in place)
-                const uint32_t slot = 4u * leaf + k;
-                bool take = t < best;
-                if (!take && bestSlot >= 0)
-                    take = __float_as_uint(b.mat[2 * slot].w) < __float_as_uint(b.mat[2 * (uint32_t)bestSlot].w);
-                if (take) { best = t; cull = t * kCullSlack; bestSlot = (int32_t)slot; }
-            }
+            // an exact tie between two spheres goes to the lower original index; the indices are fetched only then
+            // (a tie with the plane hit, bestSlot < 0, leaves the plane in place).  The update itself is three selects:
+            // as a branch the compiler carried (best, cull, bestSlot) through the loop in copies, six more moves per trip
+            const uint32_t slot = 4u * leaf + k;
+            bool take = t > kMinT && t < best;
+            if (t > kMinT && t == best && bestSlot >= 0)
+                take = __float_as_uint(b.mat[2 * slot].w) < __float_as_uint(b.mat[2 * (uint32_t)bestSlot].w);
+            best = take ? t : best; cull = take ? t * kCullSlack : cull; bestSlot = take ? (int32_t)slot : bestSlot;
         }
     }
 }

@@ -296,7 +296,11 @@ def main():
                        "resolve_into_device_image": round(min(timed_resolve(bgra.data_ptr()) for _ in range(3)), 3),
                        "copy_engine_bgra_4B_per_pixel": round(min(timed_copy(bgra_tmp, bgra) for _ in range(3)), 3),
                        "copy_engine_f32_sums_16B_per_pixel": round(min(timed_copy(accum_host, accum) for _ in range(3)), 3)}
-        assert torch.equal(bgra_tmp, bgra_host), "the image the kernel wrote into pinned host memory differs from the copied one"
+        # (the image the kernel wrote into pinned host memory during the last step against the same frame resolved on the
+        # device and copied: reported on the line, loudly on stderr if it ever differs -- never at the cost of the line)
+        readback_ms["pinned_image_equals_copied_image"] = bool(torch.equal(bgra_tmp, bgra_host))
+        if not readback_ms["pinned_image_equals_copied_image"]:
+            print("bench.py: the image resolved straight into pinned host memory DIFFERS from the copied one", file=sys.stderr)
         del accum_host, bgra_tmp
         samples_per_step = w * h * spp_all
         value = samples_per_step * args.steps / elapsed / 1e6
@@ -384,9 +388,13 @@ def main():
         }
         if world == 1 and args.cpu_spp > 0:
             threads, host = host_threads()
-            out["cpu_baseline"] = cpu_baseline(args.scene, w, h, depth, args.cpu_spp, threads, args.spheres)
-            out["cpu_baseline"]["host"] = host
-            out["config"]["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.scene, w, h, depth, args.cpu_spp, threads, args.spheres)
+                out["cpu_baseline"]["host"] = host
+                out["config"]["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+            except Exception as e:  # noqa: BLE001 - the baseline is a reported side figure: its failure must not cost the GPU line
+                print(f"bench.py: cpu_baseline failed: {e!r}", file=sys.stderr)
+                out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": threads, "kind": "failed", "sample": str(e)[:200], "host": host}
         assert host_img is not None and host_img.shape == (h, w)
         if stdout_fd is not None:
             sys.stdout.flush()

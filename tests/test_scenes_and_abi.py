@@ -182,3 +182,15 @@ def test_scene_files_round_trip_exactly(tmp_path):
             pt.Scene.load(str(bad))
     with pytest.raises(pt.PtError):
         pt.Scene.load(str(tmp_path / "missing.txt"))
+
+
+def test_both_builds_keep_the_two_flags_the_kernels_depend_on():
+    """-ffp-contract=off is parity (value-carrying arithmetic rounds like the reference's); -fno-slp-vectorize is 7 % of the
+    bench frame (the compiler otherwise pairs scalar FP32 work into half-rate packed instructions).  Makefile and
+    CMakeLists.txt must agree on both."""
+    for name, pattern in (("Makefile", r"^HIPFLAGS\s*:=\s*(.*)$"), ("CMakeLists.txt", r"^set\(PT_HIPFLAGS\s+(.*)\)$")):
+        text = open(os.path.join(ROOT, name)).read()
+        m = re.search(pattern, text, re.M)
+        assert m, name
+        flags = m.group(1).split()
+        assert "-ffp-contract=off" in flags and "-fno-slp-vectorize" in flags and "-O3" in flags, (name, flags)

@@ -234,6 +234,10 @@ pt_ctx* pt_node_ctx(pt_node* node, int gpu);   /* GPU g's context (statistics, r
  * resident sums (the next accumulating call starts from zero); so do pt_node_upload_scene and a plain pt_node_render. */
 int pt_node_snapshot(pt_node* node, float* accum_rgba_host, uint32_t* bgra_host, uint64_t* spp_out);
 int pt_node_reset(pt_node* node);
+/* Replaces: `image.pixels = memory_alloc(...)` (src/main.cpp:385), which the reference does BEFORE its timed span
+ * (src/main.cpp:412-481).  Allocates what a frame of this shape needs on every GPU -- the sums and device 0's pinned
+ * image -- ahead of the first render.  Optional: pt_node_render / pt_node_snapshot allocate on demand. */
+int pt_node_reserve(pt_node* node, uint32_t width, uint32_t height);
 /* The one-call form SURVEY.md 8(b) proposes: create + upload + render + destroy. */
 int pt_hip_render_node(const pt_scene_desc* scene, const pt_params* params, int n_gpus, float* accum_rgba_host);
 /* Host-only helper: the slice of the samples [spp_begin, spp_end) that part `part` of `n_parts` renders -- contiguous,

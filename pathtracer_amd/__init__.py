@@ -30,7 +30,7 @@ EXPORTS = (
     "pt_scene_builtin", "pt_scene_get_desc", "pt_scene_free", "pt_scene_save", "pt_scene_load",
     "pt_hip_probe_primitives", "pt_hip_probe_hits", "pt_hip_probe_get_rays", "pt_hip_probe_scatter", "pt_hip_probe_paths",
     "pt_hip_probe_samples", "pt_hip_probe_philox",
-    "pt_node_create", "pt_node_upload_scene", "pt_node_render", "pt_node_destroy", "pt_node_last_error", "pt_node_gpu_count", "pt_node_ctx", "pt_node_snapshot", "pt_node_reset",
+    "pt_node_create", "pt_node_upload_scene", "pt_node_render", "pt_node_destroy", "pt_node_last_error", "pt_node_gpu_count", "pt_node_ctx", "pt_node_snapshot", "pt_node_reset", "pt_node_reserve",
     "pt_hip_render_node", "pt_spp_slice",
 )
 
@@ -118,6 +118,7 @@ def load_library(path=LIB_PATH):
     L.pt_node_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p]
     L.pt_node_snapshot.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.pt_node_reset.argtypes = [C.c_void_p]
+    L.pt_node_reserve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     L.pt_node_destroy.argtypes = [C.c_void_p]
     L.pt_node_last_error.argtypes = [C.c_void_p]
     L.pt_node_last_error.restype = C.c_char_p
@@ -480,6 +481,11 @@ class Node:
 
     def reset(self):
         self._check(self.L.pt_node_reset(self.h), "pt_node_reset")
+
+    def reserve(self, width, height):
+        """Allocate a frame's buffers on every GPU ahead of the first render (the reference allocates its image before its
+        timed span, src/main.cpp:385)."""
+        self._check(self.L.pt_node_reserve(self.h, width, height), "pt_node_reserve")
 
     def stats(self, gpu=0):
         s = Stats()

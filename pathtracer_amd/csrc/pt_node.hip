@@ -71,7 +71,10 @@ struct pt_node
     // far; the join happens in pt_node_snapshot, out of place into snap[g], so the running sums stay per-GPU partials.
     std::vector<float*> snap; size_t snap_floats = 0;
     uint32_t res_w = 0, res_h = 0; uint64_t res_spp = 0;   // frame shape and samples per pixel of the resident sums (0 = none)
-    uint32_t* bgra_dev = nullptr; size_t bgra_pixels = 0;   // device 0
+    // The packed image: PINNED host memory that device 0 writes straight over PCIe (k_resolve), copied on to the caller's
+    // buffer by the CPU.  A hipMemcpyAsync into the caller's (pageable) memory took its place until round 3: the runtime
+    // sets that copy path up on first use -- 9 ms inside the one frame a command-line render times (profiles/README.md).
+    uint32_t* bgra_pin = nullptr; uint32_t* bgra_pin_dev = nullptr; size_t bgra_pixels = 0;
     std::vector<ncclComm_t> comm;   // empty with one GPU
     bool force_collective = false;  // PT_NODE_FORCE_COLLECTIVE=1: take the all-reduce path with one GPU too (rehearsal)
     std::string err;
@@ -121,8 +124,9 @@ int node_buffers(pt_node* nd, uint32_t w, uint32_t h)
     if ((size_t)w * h > nd->bgra_pixels)
     {
         DeviceScope s(0);
-        if (nd->bgra_dev) { (void)hipFree(nd->bgra_dev); nd->bgra_dev = nullptr; }
-        NODE_HIP(nd, hipMalloc((void**)&nd->bgra_dev, (size_t)w * h * sizeof(uint32_t)));
+        if (nd->bgra_pin) { (void)hipHostFree(nd->bgra_pin); nd->bgra_pin = nullptr; nd->bgra_pin_dev = nullptr; nd->bgra_pixels = 0; }
+        NODE_HIP(nd, hipHostMalloc((void**)&nd->bgra_pin, (size_t)w * h * sizeof(uint32_t), hipHostMallocDefault));
+        NODE_HIP(nd, hipHostGetDevicePointer((void**)&nd->bgra_pin_dev, nd->bgra_pin, 0));
         nd->bgra_pixels = (size_t)w * h;
     }
     return PT_OK;
@@ -153,7 +157,7 @@ void pt_node_destroy(pt_node* nd)
         DeviceScope s(g);
         if ((size_t)g < nd->accum.size() && nd->accum[(size_t)g]) (void)hipFree(nd->accum[(size_t)g]);
         if ((size_t)g < nd->snap.size() && nd->snap[(size_t)g]) (void)hipFree(nd->snap[(size_t)g]);
-        if (g == 0 && nd->bgra_dev) (void)hipFree(nd->bgra_dev);
+        if (g == 0 && nd->bgra_pin) (void)hipHostFree(nd->bgra_pin);
         if ((size_t)g < nd->stream.size() && nd->stream[(size_t)g]) (void)hipStreamDestroy(nd->stream[(size_t)g]);
         if ((size_t)g < nd->ctx.size() && nd->ctx[(size_t)g]) pt_hip_destroy(nd->ctx[(size_t)g]);
     }
@@ -255,9 +259,8 @@ int node_read_out(pt_node* nd, const float* sums0, uint32_t w, uint32_t h, uint6
         DeviceScope s(0);
         if (bgra_host)
         {
-            const int st = pt_hip_resolve_device(nd->ctx[0], sums0, w * h, (uint32_t)spp, nullptr, nd->bgra_dev, nd->stream[0]);
+            const int st = pt_hip_resolve_device(nd->ctx[0], sums0, w * h, (uint32_t)spp, nullptr, nd->bgra_pin_dev, nd->stream[0]);
             if (st != PT_OK) { nd->err = std::string("device 0: ") + pt_hip_last_error(nd->ctx[0]); return node_fail(nd, st); }
-            NODE_TRY_HIP(nd, hipMemcpyAsync(bgra_host, nd->bgra_dev, (size_t)w * h * sizeof(uint32_t), hipMemcpyDeviceToHost, nd->stream[0]));
         }
         if (accum_rgba_host)
             NODE_TRY_HIP(nd, hipMemcpyAsync(accum_rgba_host, sums0, floats * sizeof(float), hipMemcpyDeviceToHost, nd->stream[0]));
@@ -267,6 +270,7 @@ int node_read_out(pt_node* nd, const float* sums0, uint32_t w, uint32_t h, uint6
         DeviceScope s(g);
         NODE_TRY_HIP(nd, hipStreamSynchronize(nd->stream[(size_t)g]));
     }
+    if (bgra_host) memcpy(bgra_host, nd->bgra_pin, (size_t)w * h * sizeof(uint32_t));
     return PT_OK;
 }
 
@@ -351,6 +355,15 @@ int pt_node_snapshot(pt_node* nd, float* accum_rgba_host, uint32_t* bgra_host, u
     const int st = node_read_out(nd, sums0, w, h, nd->res_spp, accum_rgba_host, bgra_host);
     if (st == PT_OK) nd->res_spp = keep;
     return st;
+    NODE_LEAVE
+}
+
+int pt_node_reserve(pt_node* nd, uint32_t width, uint32_t height)
+{
+    if (!nd || width == 0 || height == 0) return PT_ERR_INVALID;
+    NODE_ENTER(nd, "pt_node_reserve")
+    nd->err.clear();
+    return node_buffers(nd, width, height);
     NODE_LEAVE
 }
 

@@ -107,6 +107,8 @@ int main(int argc, char** argv)
     pt_params p{};
     p.width = o.width; p.height = o.height; p.max_depth = o.depth; p.flags = o.flags; p.seed = o.seed; p.spp_begin = 0; p.spp_end = o.spp;
     std::vector<uint32_t> bgra((size_t)o.width * o.height);
+    st = pt_node_reserve(node, o.width, o.height);   // the image is allocated before the span, as in the reference (src/main.cpp:385)
+    if (st != PT_OK) { fprintf(stderr, "pt_render: %s (%s)\n", pt_hip_strerror(st), pt_node_last_error(node)); return 1; }
     const auto tRender = std::chrono::steady_clock::now();
     if (o.pieces > 1)
     {

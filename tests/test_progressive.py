@@ -39,6 +39,24 @@ def test_node_upload_builds_the_tree_once():
         assert pt.tree_build_count() == before + 1
 
 
+def test_node_reserve_and_the_pinned_image(renderer):
+    """pt_node_reserve allocates a frame's buffers ahead of the render (the reference allocates its image before its timed
+    span, main.cpp:385); the packed image device 0 writes into the node's pinned memory is the one pt_hip_resolve + pack
+    give for the same sums -- at a first shape, at a bigger one (buffers re-grown) and at a smaller one (kept)."""
+    scene = pt.Scene.builtin(1, 16 / 9)
+    with pt.Node(1) as node:
+        node.upload(scene)
+        with pytest.raises(pt.PtError) as e:
+            node.reserve(0, 4)
+        assert e.value.status == pt.PT_ERR_INVALID
+        node.reserve(64, 36)
+        for w, h in ((64, 36), (160, 90), (32, 18)):
+            sums, bgra = node.render(w, h, 0, 8, 10, seed=5, flags=pt.FLAG_REPRODUCIBLE, want_bgra=True)
+            assert np.allclose(sums[..., 3], 8)
+            want = pt.pack_bgra(pt.resolve(sums, 8)).reshape(h, w)
+            assert (bgra == want).all(), (w, h)
+
+
 @pytest.mark.parametrize("flags", [pt.FLAG_REPRODUCIBLE, 0, pt.FLAG_REPRODUCIBLE | pt.FLAG_FORCE_BVH])
 def test_accumulate_flag_adds_pieces_into_one_buffer(renderer, flags):
     """pt_hip_render_device with PT_FLAG_ACCUMULATE: 4 pieces into one resident buffer == the pieces rendered apart and
